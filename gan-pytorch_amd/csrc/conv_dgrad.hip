@@ -1,0 +1,37 @@
+// vg_conv2d_dgrad: gx = conv_transpose(gy, w) (+ bias): the gradient of a convolution with respect to its
+// input, which is also the forward pass of ConvTranspose2d.
+#include "igemm.h"
+
+int vg_gemm_kn(const float* A, const float* B, const float* bias, int bias_mod, float* out, int M, int Ncols, int K,
+               hipStream_t stream);
+
+extern "C" int vg_conv2d_dgrad(const vg_conv_geom* g, const float* gy, const float* w, const float* bias,
+                               float* gx, void* stream) {
+  if (int e = vg_check_geom(g, "vg_conv2d_dgrad")) return e;
+  VG_REQUIRE(gy && w && gx, "vg_conv2d_dgrad: null tensor pointer");
+
+  // 1x1 gradient image covering the whole input window: one GEMM [N][Co] x [Co][kh*kw*Ci].
+  if (g->Ho == 1 && g->Wo == 1 && g->ph == 0 && g->pw == 0 && g->H == g->kh && g->W == g->kw)
+    return vg_gemm_kn(gy, w, bias, g->Ci, gx, g->N, g->kh * g->kw * g->Ci, g->Co, (hipStream_t)stream);
+
+  IgemmParams p{};
+  p.A = gy; p.B = w; p.bias = bias; p.out = gx;
+  p.N = g->N; p.H = g->H; p.W = g->W; p.Ci = g->Ci; p.Co = g->Co; p.KH = g->kh; p.KW = g->kw;
+  p.Ho = g->Ho; p.Wo = g->Wo; p.sh = g->sh; p.sw = g->sw; p.ph = g->ph; p.pw = g->pw;
+  p.Ncols = g->Ci;
+  p.bias_mod = g->Ci;
+  // Largest parity class bounds the grid; smaller classes retire their surplus blocks at entry.
+  const int Hc = (g->H + g->sh - 1) / g->sh, Wc = (g->W + g->sw - 1) / g->sw;
+  p.M = g->N * Hc * Wc;
+  p.Ktot = 0;  // per class, derived in the kernel
+  const int bn = igemm_pick_bn(p.Ncols);
+  p.mtiles = (p.M + 127) / 128;
+  p.ntiles = (p.Ncols + bn - 1) / bn;
+  const int va = (g->Co % 4 == 0 && vg_aligned16(gy)) ? 4 : 1;
+  const int vb = (g->Ci % 4 == 0 && vg_aligned16(w)) ? 4 : 1;
+  dim3 grid((unsigned)(p.mtiles * p.ntiles), 1, (unsigned)(g->sh * g->sw));
+  if (igemm_launch<MODE_DGRAD, true>(p, bn, va, vb, grid, (hipStream_t)stream) != 0)
+    return vg_fail(VG_ERR_INVALID, "vg_conv2d_dgrad: no kernel variant for bn=%d va=%d vb=%d", bn, va, vb);
+  VG_CHECK_LAUNCH("vg_conv2d_dgrad");
+  return VG_OK;
+}

@@ -1,0 +1,64 @@
+// vg_conv2d_fwd: y = conv(x, w) + bias on the f32 MFMA implicit-GEMM core.
+#include "igemm.h"
+
+int vg_check_geom(const vg_conv_geom* g, const char* who) {
+  if (!g) return vg_fail(VG_ERR_INVALID, "%s: null geometry", who);
+  if (g->N <= 0 || g->H <= 0 || g->W <= 0 || g->Ci <= 0 || g->Co <= 0 || g->kh <= 0 || g->kw <= 0 ||
+      g->sh <= 0 || g->sw <= 0 || g->ph < 0 || g->pw < 0 || g->Ho <= 0 || g->Wo <= 0)
+    return vg_fail(VG_ERR_INVALID, "%s: non-positive extent in geometry", who);
+  if ((g->H + 2 * g->ph - g->kh) / g->sh + 1 != g->Ho || (g->W + 2 * g->pw - g->kw) / g->sw + 1 != g->Wo ||
+      g->H + 2 * g->ph < g->kh || g->W + 2 * g->pw < g->kw)
+    return vg_fail(VG_ERR_INVALID, "%s: Ho/Wo (%d,%d) inconsistent with H,W,k,s,p", who, g->Ho, g->Wo);
+  const long long in_elems = (long long)g->N * g->H * g->W * g->Ci;
+  const long long out_elems = (long long)g->N * g->Ho * g->Wo * g->Co;
+  const long long w_elems = (long long)g->Co * g->kh * g->kw * g->Ci;
+  if (in_elems >= (1LL << 31) || out_elems >= (1LL << 31) || w_elems >= (1LL << 31))
+    return vg_fail(VG_ERR_INVALID, "%s: tensor exceeds 2^31 elements", who);
+  return 0;
+}
+
+extern "C" int vg_conv2d_fwd(const vg_conv_geom* g, const float* x, const float* w, const float* bias,
+                             float* y, void* stream) {
+  if (int e = vg_check_geom(g, "vg_conv2d_fwd")) return e;
+  VG_REQUIRE(x && w && y, "vg_conv2d_fwd: null tensor pointer");
+  IgemmParams p{};
+  p.A = x; p.B = w; p.bias = bias; p.out = y;
+  p.N = g->N; p.H = g->H; p.W = g->W; p.Ci = g->Ci; p.Co = g->Co; p.KH = g->kh; p.KW = g->kw;
+  p.Ho = g->Ho; p.Wo = g->Wo; p.sh = g->sh; p.sw = g->sw; p.ph = g->ph; p.pw = g->pw;
+  p.M = g->N * g->Ho * g->Wo;
+  p.Ncols = g->Co;
+  p.Ktot = g->kh * g->kw * g->Ci;
+  p.bias_mod = g->Co;
+  const int bn = igemm_pick_bn(p.Ncols);
+  p.mtiles = (p.M + 127) / 128;
+  p.ntiles = (p.Ncols + bn - 1) / bn;
+  const int va = (g->Ci % 4 == 0 && vg_aligned16(x)) ? 4 : 1;
+  const int vb = (p.Ktot % 4 == 0 && vg_aligned16(w)) ? 4 : 1;
+  dim3 grid((unsigned)(p.mtiles * p.ntiles), 1, 1);
+  if (igemm_launch<MODE_FWD, false>(p, bn, va, vb, grid, (hipStream_t)stream) != 0)
+    return vg_fail(VG_ERR_INVALID, "vg_conv2d_fwd: no kernel variant for bn=%d va=%d vb=%d", bn, va, vb);
+  VG_CHECK_LAUNCH("vg_conv2d_fwd");
+  return VG_OK;
+}
+
+// Plain GEMM out[M][Ncols] = A[M][K] * B[K][Ncols] (+ bias[col % bias_mod]); used by vg_conv2d_dgrad when the
+// gradient image is 1x1 (ConvTranspose2d applied to a latent vector): every tap then hits exactly one output
+// pixel and the transposed convolution is a single GEMM against the weight viewed as [Co][kh*kw*Ci].
+int vg_gemm_kn(const float* A, const float* B, const float* bias, int bias_mod, float* out, int M, int Ncols, int K,
+               hipStream_t stream) {
+  IgemmParams p{};
+  p.A = A; p.B = B; p.bias = bias; p.out = out;
+  p.N = M; p.H = 1; p.W = 1; p.Ci = K; p.Co = Ncols; p.KH = 1; p.KW = 1;
+  p.Ho = 1; p.Wo = 1; p.sh = 1; p.sw = 1; p.ph = 0; p.pw = 0;
+  p.M = M; p.Ncols = Ncols; p.Ktot = K; p.bias_mod = bias_mod;
+  const int bn = igemm_pick_bn(Ncols);
+  p.mtiles = (M + 127) / 128;
+  p.ntiles = (Ncols + bn - 1) / bn;
+  const int va = (K % 4 == 0 && vg_aligned16(A)) ? 4 : 1;
+  const int vb = (Ncols % 4 == 0 && vg_aligned16(B)) ? 4 : 1;
+  dim3 grid((unsigned)(p.mtiles * p.ntiles), 1, 1);
+  if (igemm_launch<MODE_FWD, true>(p, bn, va, vb, grid, stream) != 0)
+    return vg_fail(VG_ERR_INVALID, "vg_gemm_kn: no kernel variant for bn=%d va=%d vb=%d", bn, va, vb);
+  VG_CHECK_LAUNCH("vg_gemm_kn");
+  return VG_OK;
+}

@@ -1,0 +1,163 @@
+// Layout copies (NCHW <-> NHWC), channel concatenate / slice for conditional inputs, small elementwise helpers,
+// and the library's error reporting.
+#include "vg_internal.h"
+
+#include <string.h>
+
+char* vg_error_buffer() {
+  static thread_local char buf[512] = {0};
+  return buf;
+}
+
+int vg_fail(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(vg_error_buffer(), 512, fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+extern "C" const char* vg_last_error(void) { return vg_error_buffer(); }
+extern "C" int vg_abi_version(void) { return 1; }
+
+namespace {
+
+// Per image: src [R][S] -> dst [S][R] through a 32x33 LDS tile (coalesced on both sides).
+__global__ void __launch_bounds__(256) transpose_kernel(const float* __restrict__ src, float* __restrict__ dst, int R, int S) {
+  __shared__ float tile[32][33];
+  const size_t img = (size_t)blockIdx.z * R * S;
+  const int s0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+#pragma unroll
+  for (int j = 0; j < 32; j += 8) {
+    const int rr = r0 + ty + j, ss = s0 + tx;
+    if (rr < R && ss < S) tile[ty + j][tx] = src[img + (size_t)rr * S + ss];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < 32; j += 8) {
+    const int ss = s0 + ty + j, rr = r0 + tx;
+    if (rr < R && ss < S) dst[img + (size_t)ss * R + rr] = tile[tx][ty + j];
+  }
+}
+
+int launch_transpose(const char* who, const float* src, float* dst, int N, int R, int S, hipStream_t st) {
+  if (!(src && dst && N > 0 && R > 0 && S > 0)) return vg_fail(VG_ERR_INVALID, "%s: bad arguments", who);
+  if (N > 65535) return vg_fail(VG_ERR_INVALID, "%s: batch %d exceeds the grid z limit", who, N);
+  dim3 grid((S + 31) / 32, (R + 31) / 32, N);
+  hipLaunchKernelGGL(transpose_kernel, grid, dim3(256), 0, st, src, dst, R, S);
+  VG_CHECK_LAUNCH(who);
+  return VG_OK;
+}
+
+__global__ void __launch_bounds__(256) concat_kernel(const float* __restrict__ a, int C1, int a_bcast, const float* __restrict__ b,
+                                                     int C2, int b_bcast, float* __restrict__ out, size_t total, int HW) {
+  const int Ct = C1 + C2;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const size_t pix = i / Ct;
+    const int c = (int)(i - pix * Ct);
+    const size_t n = pix / HW;
+    float v;
+    if (c < C1) v = a_bcast ? a[n * C1 + c] : a[pix * C1 + c];
+    else v = b_bcast ? b[n * C2 + (c - C1)] : b[pix * C2 + (c - C1)];
+    out[i] = v;
+  }
+}
+
+__global__ void __launch_bounds__(256) slice_kernel(const float* __restrict__ src, int Ct, int c0, int Cp, float* __restrict__ dst,
+                                                    size_t total) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const size_t pix = i / Cp;
+    const int c = (int)(i - pix * Cp);
+    dst[i] = src[pix * Ct + c0 + c];
+  }
+}
+
+__global__ void __launch_bounds__(256) add_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out,
+                                                  size_t n) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) out[i] = a[i] + b[i];
+}
+
+__global__ void __launch_bounds__(256) scale_kernel(const float* __restrict__ a, float s, float* __restrict__ out, size_t n) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) out[i] = a[i] * s;
+}
+
+__global__ void __launch_bounds__(256) fill_kernel(float* __restrict__ out, float v, size_t n) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) out[i] = v;
+}
+
+// out[0] = c0*a[0] + c1*b[0] + c2*c[0] (b, c nullable); aux[0] = a[0]/b[0] if aux: the scalar epilogue of the
+// adversary loss: 0.5*(fake+real) + lambda*penalty and the logged real/fake ratio, without leaving the device.
+__global__ void scalar_combine_kernel(const float* a, float c0, const float* b, float c1, const float* c, float c2, float* out,
+                                      float* ratio_b_over_a) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    float v = c0 * a[0];
+    if (b) v += c1 * b[0];
+    if (c) v += c2 * c[0];
+    out[0] = v;
+    if (ratio_b_over_a && b) ratio_b_over_a[0] = b[0] / a[0];
+  }
+}
+
+}  // namespace
+
+extern "C" int vg_nchw_to_nhwc(const float* src, float* dst, int N, int C, int HW, void* stream) {
+  return launch_transpose("vg_nchw_to_nhwc", src, dst, N, C, HW, (hipStream_t)stream);
+}
+
+extern "C" int vg_nhwc_to_nchw(const float* src, float* dst, int N, int C, int HW, void* stream) {
+  return launch_transpose("vg_nhwc_to_nchw", src, dst, N, HW, C, (hipStream_t)stream);
+}
+
+extern "C" int vg_concat_channels(const float* a, int C1, int a_bcast, const float* b, int C2, int b_bcast, float* out, int N,
+                                  int HW, void* stream) {
+  VG_REQUIRE(a && b && out && C1 > 0 && C2 > 0 && N > 0 && HW > 0, "vg_concat_channels: bad arguments");
+  const size_t total = (size_t)N * HW * (C1 + C2);
+  hipLaunchKernelGGL(concat_kernel, dim3(vg_stream_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, a, C1, a_bcast, b, C2,
+                     b_bcast, out, total, HW);
+  VG_CHECK_LAUNCH("vg_concat_channels");
+  return VG_OK;
+}
+
+extern "C" int vg_slice_channels(const float* src, int Ctot, int c0, int Cp, float* dst, size_t pixels, void* stream) {
+  VG_REQUIRE(src && dst && Ctot > 0 && c0 >= 0 && Cp > 0 && c0 + Cp <= Ctot && pixels > 0, "vg_slice_channels: bad arguments");
+  const size_t total = pixels * Cp;
+  hipLaunchKernelGGL(slice_kernel, dim3(vg_stream_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, src, Ctot, c0, Cp, dst,
+                     total);
+  VG_CHECK_LAUNCH("vg_slice_channels");
+  return VG_OK;
+}
+
+extern "C" int vg_add(const float* a, const float* b, float* out, size_t n, void* stream) {
+  VG_REQUIRE(a && b && out && n > 0, "vg_add: bad arguments");
+  hipLaunchKernelGGL(add_kernel, dim3(vg_stream_grid(n, 256)), dim3(256), 0, (hipStream_t)stream, a, b, out, n);
+  VG_CHECK_LAUNCH("vg_add");
+  return VG_OK;
+}
+
+extern "C" int vg_scale(const float* a, float s, float* out, size_t n, void* stream) {
+  VG_REQUIRE(a && out && n > 0, "vg_scale: bad arguments");
+  hipLaunchKernelGGL(scale_kernel, dim3(vg_stream_grid(n, 256)), dim3(256), 0, (hipStream_t)stream, a, s, out, n);
+  VG_CHECK_LAUNCH("vg_scale");
+  return VG_OK;
+}
+
+extern "C" int vg_fill(float* out, float v, size_t n, void* stream) {
+  VG_REQUIRE(out && n > 0, "vg_fill: bad arguments");
+  hipLaunchKernelGGL(fill_kernel, dim3(vg_stream_grid(n, 256)), dim3(256), 0, (hipStream_t)stream, out, v, n);
+  VG_CHECK_LAUNCH("vg_fill");
+  return VG_OK;
+}
+
+extern "C" int vg_scalar_combine(const float* a, float c0, const float* b, float c1, const float* c, float c2, float* out,
+                                 float* ratio_b_over_a, void* stream) {
+  VG_REQUIRE(a && out, "vg_scalar_combine: bad arguments");
+  hipLaunchKernelGGL(scalar_combine_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, a, c0, b, c1, c, c2, out, ratio_b_over_a);
+  VG_CHECK_LAUNCH("vg_scalar_combine");
+  return VG_OK;
+}

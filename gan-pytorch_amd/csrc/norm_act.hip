@@ -1,0 +1,583 @@
+// BatchNorm (training/eval), activations and per-channel reductions over NHWC activations viewed as
+// x[M][C] (M = N*H*W).  All of these are HBM-bound: 16-byte accesses, consecutive lanes on consecutive
+// addresses, and every cross-block reduction goes through per-block partials that a second kernel adds in
+// block order, so results are bitwise reproducible (no float atomics).
+#include "vg_internal.h"
+
+namespace {
+
+constexpr int kMaxRowBlocks = 512;
+
+inline int row_blocks(int M) {
+  // at least 64 rows per block; at most kMaxRowBlocks blocks
+  int nb = (M + 63) / 64;
+  if (nb > kMaxRowBlocks) nb = kMaxRowBlocks;
+  if (nb < 1) nb = 1;
+  return nb;
+}
+
+// ---- generic column reduction: partial[v][b][c] = sum over the rows of block b of f_v(row, c) -------------
+template <int NV, int VEC, class F>
+__global__ void __launch_bounds__(256) colreduce_partial(F f, int M, int C, int rows_per_block, float* partial) {
+  __shared__ float red[NV * VEC * 256];
+  const int CG = C / VEC;
+  const int TX = CG < 256 ? CG : 256;
+  const int TY = 256 / TX;
+  const int tid = threadIdx.x;
+  const int tx = tid % TX, ty = tid / TX;
+  const int nblk = gridDim.x;
+  const int row0 = blockIdx.x * rows_per_block;
+  const int row1 = min(row0 + rows_per_block, M);
+  for (int cg0 = 0; cg0 < CG; cg0 += TX) {
+    const int cg = cg0 + tx;
+    float acc[NV][VEC];
+#pragma unroll
+    for (int v = 0; v < NV; ++v)
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) acc[v][e] = 0.f;
+    if (ty < TY && cg < CG) {
+#pragma unroll 4
+      for (int row = row0 + ty; row < row1; row += TY) f.template eval<VEC>((size_t)row * C + (size_t)cg * VEC, cg * VEC, acc);
+    }
+#pragma unroll
+    for (int v = 0; v < NV; ++v)
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) red[(v * VEC + e) * 256 + tid] = acc[v][e];
+    __syncthreads();
+    if (ty == 0 && cg < CG) {
+#pragma unroll
+      for (int v = 0; v < NV; ++v)
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+          float s = 0.f;
+          for (int y = 0; y < TY; ++y) s += red[(v * VEC + e) * 256 + y * TX + tx];
+          partial[((size_t)v * nblk + blockIdx.x) * C + cg * VEC + e] = s;
+        }
+    }
+    __syncthreads();
+  }
+}
+
+// out[v][c] = sum_b partial[v][b][c]; 64 channels x 4 block-lanes per workgroup, fixed summation order.
+template <int NV>
+__global__ void __launch_bounds__(256) colreduce_final(const float* partial, int nblk, int C, float* out) {
+  __shared__ float red[NV * 256];
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int q = threadIdx.x >> 6;
+  float acc[NV];
+#pragma unroll
+  for (int v = 0; v < NV; ++v) acc[v] = 0.f;
+  if (c < C) {
+    for (int b = q; b < nblk; b += 4) {
+#pragma unroll
+      for (int v = 0; v < NV; ++v) acc[v] += partial[((size_t)v * nblk + b) * C + c];
+    }
+  }
+#pragma unroll
+  for (int v = 0; v < NV; ++v) red[v * 256 + threadIdx.x] = acc[v];
+  __syncthreads();
+  if (q == 0 && c < C) {
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+      const float* rr = red + v * 256 + (threadIdx.x & 63);
+      out[(size_t)v * C + c] = (rr[0] + rr[64]) + (rr[128] + rr[192]);
+    }
+  }
+}
+
+template <int NV, class F>
+int run_colreduce(const char* who, F f, int M, int C, bool vec_ok, float* out, void* ws, size_t ws_bytes,
+                  hipStream_t st) {
+  const int nb = row_blocks(M);
+  const size_t need = (size_t)NV * nb * C * sizeof(float);
+  if (!ws || ws_bytes < need) return vg_fail(VG_ERR_WORKSPACE, "%s: workspace of %zu bytes required, got %zu", who, need, ws_bytes);
+  const int rpb = (M + nb - 1) / nb;
+  float* partial = (float*)ws;
+  if (vec_ok && C % 4 == 0)
+    hipLaunchKernelGGL((colreduce_partial<NV, 4, F>), dim3(nb), dim3(256), 0, st, f, M, C, rpb, partial);
+  else
+    hipLaunchKernelGGL((colreduce_partial<NV, 1, F>), dim3(nb), dim3(256), 0, st, f, M, C, rpb, partial);
+  VG_CHECK_LAUNCH(who);
+  hipLaunchKernelGGL((colreduce_final<NV>), dim3((C + 63) / 64), dim3(256), 0, st, (const float*)partial, nb, C, out);
+  VG_CHECK_LAUNCH(who);
+  return VG_OK;
+}
+
+template <int VEC>
+__device__ __forceinline__ void ldv(const float* p, float (&v)[VEC]) {
+  if constexpr (VEC == 4) {
+    const f32x4 t = *reinterpret_cast<const f32x4*>(p);
+    v[0] = t[0]; v[1] = t[1]; v[2] = t[2]; v[3] = t[3];
+  } else {
+    v[0] = *p;
+  }
+}
+template <int VEC>
+__device__ __forceinline__ void stv(float* p, const float (&v)[VEC]) {
+  if constexpr (VEC == 4) {
+    f32x4 t = {v[0], v[1], v[2], v[3]};
+    *reinterpret_cast<f32x4*>(p) = t;
+  } else {
+    *p = v[0];
+  }
+}
+
+// ---- functors -------------------------------------------------------------------------------------
+struct SumF {  // colsum
+  const float* x;
+  template <int VEC>
+  __device__ void eval(size_t off, int c, float (&acc)[1][VEC]) const {
+    float a[VEC];
+    ldv<VEC>(x + off, a);
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) acc[0][e] += a[e];
+  }
+};
+
+struct ShiftedMomentsF {  // sums of (x - x[0][c]) and its square
+  const float* x;
+  template <int VEC>
+  __device__ void eval(size_t off, int c, float (&acc)[2][VEC]) const {
+    float a[VEC], s[VEC];
+    ldv<VEC>(x + off, a);
+    ldv<VEC>(x + c, s);
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+      const float d = a[e] - s[e];
+      acc[0][e] += d;
+      acc[1][e] = fmaf(d, d, acc[1][e]);
+    }
+  }
+};
+
+struct BnBwdF {  // sum gy, sum gy*xhat
+  const float *gy, *x, *mean, *invstd;
+  template <int VEC>
+  __device__ void eval(size_t off, int c, float (&acc)[2][VEC]) const {
+    float g[VEC], a[VEC], mu[VEC], r[VEC];
+    ldv<VEC>(gy + off, g);
+    ldv<VEC>(x + off, a);
+    ldv<VEC>(mean + c, mu);
+    ldv<VEC>(invstd + c, r);
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+      const float xh = (a[e] - mu[e]) * r[e];
+      acc[0][e] += g[e];
+      acc[1][e] = fmaf(g[e], xh, acc[1][e]);
+    }
+  }
+};
+
+struct BnDbwdF {  // sum gy, sum gy*xhat, sum u, sum u*xhat, sum u*gy
+  const float *gy, *x, *u, *mean, *invstd;
+  template <int VEC>
+  __device__ void eval(size_t off, int c, float (&acc)[5][VEC]) const {
+    float g[VEC], a[VEC], uu[VEC], mu[VEC], r[VEC];
+    ldv<VEC>(gy + off, g);
+    ldv<VEC>(x + off, a);
+    ldv<VEC>(u + off, uu);
+    ldv<VEC>(mean + c, mu);
+    ldv<VEC>(invstd + c, r);
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+      const float xh = (a[e] - mu[e]) * r[e];
+      acc[0][e] += g[e];
+      acc[1][e] = fmaf(g[e], xh, acc[1][e]);
+      acc[2][e] += uu[e];
+      acc[3][e] = fmaf(uu[e], xh, acc[3][e]);
+      acc[4][e] = fmaf(uu[e], g[e], acc[4][e]);
+    }
+  }
+};
+
+// ---- BatchNorm statistics -------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) bn_finalize_kernel(const float* x, const float* sums /*[2][C]*/, int M, int C,
+                                                          float eps, float momentum, float* mean, float* invstd,
+                                                          float* running_mean, float* running_var) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const float n = (float)M;
+  const float shift = x[c];
+  const float s1 = sums[c] / n;
+  float var = sums[C + c] / n - s1 * s1;
+  var = var < 0.f ? 0.f : var;
+  const float mu = shift + s1;
+  mean[c] = mu;
+  invstd[c] = 1.0f / sqrtf(var + eps);
+  if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mu;
+  if (running_var) {
+    const float unbiased = M > 1 ? var * (n / (n - 1.f)) : var;
+    running_var[c] = (1.f - momentum) * running_var[c] + momentum * unbiased;
+  }
+}
+
+__global__ void __launch_bounds__(256) invstd_kernel(const float* var, float* invstd, int C, float eps) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c < C) invstd[c] = 1.0f / sqrtf(var[c] + eps);
+}
+
+// ---- elementwise -----------------------------------------------------------------------------------
+__device__ __forceinline__ float act_apply(float v, int act, float slope) {
+  switch (act) {
+    case VG_ACT_RELU: return v > 0.f ? v : 0.f;
+    case VG_ACT_LRELU: return v > 0.f ? v : v * slope;
+    case VG_ACT_TANH: return tanhf(v);
+    case VG_ACT_SIGMOID: return 1.0f / (1.0f + expf(-v));
+    default: return v;
+  }
+}
+
+// gx factor; `ref` = forward input (relu/lrelu) or forward output (tanh/sigmoid)
+__device__ __forceinline__ float act_grad(float ref, int act, float slope) {
+  switch (act) {
+    case VG_ACT_RELU: return ref > 0.f ? 1.f : 0.f;
+    case VG_ACT_LRELU: return ref > 0.f ? 1.f : slope;
+    case VG_ACT_TANH: return 1.f - ref * ref;
+    case VG_ACT_SIGMOID: return ref * (1.f - ref);
+    default: return 1.f;
+  }
+}
+
+template <int VEC>
+__global__ void __launch_bounds__(256) bn_apply_kernel(const float* __restrict__ x, const float* __restrict__ mean,
+                                                       const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                                       const float* __restrict__ beta, float* __restrict__ y, size_t nvec,
+                                                       int C, int act, float slope) {
+  const int CG = C / VEC;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += stride) {
+    const int c = (int)(i % CG) * VEC;
+    float a[VEC], mu[VEC], r[VEC], ga[VEC], be[VEC], o[VEC];
+    ldv<VEC>(x + i * VEC, a);
+    ldv<VEC>(mean + c, mu);
+    ldv<VEC>(invstd + c, r);
+    if (gamma) ldv<VEC>(gamma + c, ga);
+    if (beta) ldv<VEC>(beta + c, be);
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+      const float sc = gamma ? r[e] * ga[e] : r[e];
+      float v = (a[e] - mu[e]) * sc;
+      if (beta) v += be[e];
+      o[e] = act_apply(v, act, slope);
+    }
+    stv<VEC>(y + i * VEC, o);
+  }
+}
+
+template <int VEC>
+__global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const float* __restrict__ gy, const float* __restrict__ x,
+                                                           const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                           const float* __restrict__ gamma, const float* __restrict__ sums,
+                                                           float* __restrict__ gx, size_t nvec, int C, float inv_n) {
+  const int CG = C / VEC;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += stride) {
+    const int c = (int)(i % CG) * VEC;
+    float g[VEC], a[VEC], mu[VEC], r[VEC], ga[VEC], sg[VEC], sgx[VEC], o[VEC];
+    ldv<VEC>(gy + i * VEC, g);
+    ldv<VEC>(x + i * VEC, a);
+    ldv<VEC>(mean + c, mu);
+    ldv<VEC>(invstd + c, r);
+    if (gamma) ldv<VEC>(gamma + c, ga);
+    ldv<VEC>(sums + c, sg);
+    ldv<VEC>(sums + C + c, sgx);
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+      const float xh = (a[e] - mu[e]) * r[e];
+      const float sc = gamma ? r[e] * ga[e] : r[e];
+      o[e] = sc * (g[e] - sg[e] * inv_n - xh * (sgx[e] * inv_n));
+    }
+    stv<VEC>(gx + i * VEC, o);
+  }
+}
+
+template <int VEC>
+__global__ void __launch_bounds__(256) bn_bwd_eval_kernel(const float* __restrict__ gy, const float* __restrict__ invstd,
+                                                          const float* __restrict__ gamma, float* __restrict__ gx,
+                                                          size_t nvec, int C) {
+  const int CG = C / VEC;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += stride) {
+    const int c = (int)(i % CG) * VEC;
+    float g[VEC], r[VEC], ga[VEC], o[VEC];
+    ldv<VEC>(gy + i * VEC, g);
+    ldv<VEC>(invstd + c, r);
+    if (gamma) ldv<VEC>(gamma + c, ga);
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) o[e] = g[e] * (gamma ? r[e] * ga[e] : r[e]);
+    stv<VEC>(gx + i * VEC, o);
+  }
+}
+
+// second derivative of the training-mode backward (see vegans_hip.h for the meaning of u, v, w)
+template <int VEC>
+__global__ void __launch_bounds__(256) bn_dbwd_apply_kernel(
+    const float* __restrict__ gy, const float* __restrict__ x, const float* __restrict__ u, const float* __restrict__ v,
+    const float* __restrict__ w, const float* __restrict__ mean, const float* __restrict__ invstd,
+    const float* __restrict__ gamma, const float* __restrict__ sums5, float* __restrict__ d_gy, float* __restrict__ d_x,
+    size_t nvec, int C, float inv_n) {
+  const int CG = C / VEC;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += stride) {
+    const int c = (int)(i % CG) * VEC;
+    float g[VEC], a[VEC], uu[VEC], mu[VEC], r[VEC], ga[VEC], vv[VEC], ww[VEC];
+    float s0[VEC], s1[VEC], s2[VEC], s3[VEC], s4[VEC], o1[VEC], o2[VEC];
+    ldv<VEC>(gy + i * VEC, g);
+    ldv<VEC>(x + i * VEC, a);
+    ldv<VEC>(u + i * VEC, uu);
+    ldv<VEC>(mean + c, mu);
+    ldv<VEC>(invstd + c, r);
+    if (gamma) ldv<VEC>(gamma + c, ga);
+    if (v) ldv<VEC>(v + c, vv);
+    if (w) ldv<VEC>(w + c, ww);
+    ldv<VEC>(sums5 + c, s0);
+    ldv<VEC>(sums5 + C + c, s1);
+    ldv<VEC>(sums5 + 2 * C + c, s2);
+    ldv<VEC>(sums5 + 3 * C + c, s3);
+    ldv<VEC>(sums5 + 4 * C + c, s4);
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+      const float xh = (a[e] - mu[e]) * r[e];
+      const float gam = gamma ? ga[e] : 1.f;
+      const float gbar = s0[e] * inv_n, m = s1[e] * inv_n, ubar = s2[e] * inv_n, q = s3[e] * inv_n;
+      const float P = s4[e] * inv_n - ubar * gbar - q * m;
+      const float du = uu[e] - ubar, dg = g[e] - gbar;
+      float ogy = gam * r[e] * (du - xh * q);
+      float ox = -gam * r[e] * r[e] * (m * du + q * dg + xh * (P - 2.f * m * q));
+      if (v) {
+        ogy += vv[e] * xh;
+        ox += vv[e] * r[e] * (dg - xh * m);
+      }
+      if (w) ogy += ww[e];
+      o1[e] = ogy;
+      o2[e] = ox;
+    }
+    stv<VEC>(d_gy + i * VEC, o1);
+    stv<VEC>(d_x + i * VEC, o2);
+  }
+}
+
+__global__ void __launch_bounds__(256) bn_dbwd_gamma_kernel(const float* invstd, const float* sums5, float* d_gamma, int C,
+                                                            float n) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const float inv_n = 1.f / n;
+  const float gbar = sums5[c] * inv_n, m = sums5[C + c] * inv_n, ubar = sums5[2 * C + c] * inv_n, q = sums5[3 * C + c] * inv_n;
+  const float P = sums5[4 * C + c] * inv_n - ubar * gbar - q * m;
+  d_gamma[c] = invstd[c] * n * P;
+}
+
+template <int VEC>
+__global__ void __launch_bounds__(256) act_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, size_t nvec, int act,
+                                                      float slope) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += stride) {
+    float a[VEC], o[VEC];
+    ldv<VEC>(x + i * VEC, a);
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) o[e] = act_apply(a[e], act, slope);
+    stv<VEC>(y + i * VEC, o);
+  }
+}
+
+template <int VEC>
+__global__ void __launch_bounds__(256) act_bwd_kernel(const float* __restrict__ gy, const float* __restrict__ ref,
+                                                      float* __restrict__ gx, size_t nvec, int act, float slope) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += stride) {
+    float g[VEC], a[VEC], o[VEC];
+    ldv<VEC>(gy + i * VEC, g);
+    ldv<VEC>(ref + i * VEC, a);
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) o[e] = g[e] * act_grad(a[e], act, slope);
+    stv<VEC>(gx + i * VEC, o);
+  }
+}
+
+template <int VEC>
+__global__ void __launch_bounds__(256) act_dbwd_ref_kernel(const float* __restrict__ gg, const float* __restrict__ gy,
+                                                           const float* __restrict__ ref, float* __restrict__ d_ref,
+                                                           size_t nvec, int act) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += stride) {
+    float a[VEC], b[VEC], y[VEC], o[VEC];
+    ldv<VEC>(gg + i * VEC, a);
+    ldv<VEC>(gy + i * VEC, b);
+    ldv<VEC>(ref + i * VEC, y);
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+      const float f = act == VG_ACT_TANH ? -2.f * y[e] : (act == VG_ACT_SIGMOID ? 1.f - 2.f * y[e] : 0.f);
+      o[e] = a[e] * b[e] * f;
+    }
+    stv<VEC>(d_ref + i * VEC, o);
+  }
+}
+
+template <int VEC>
+__global__ void __launch_bounds__(256) bcast_rows_kernel(const float* __restrict__ v, float* __restrict__ out, size_t nvec,
+                                                         int C) {
+  const int CG = C / VEC;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += stride) {
+    float a[VEC];
+    ldv<VEC>(v + (int)(i % CG) * VEC, a);
+    stv<VEC>(out + i * VEC, a);
+  }
+}
+
+inline bool all_aligned(std::initializer_list<const void*> ps) {
+  for (const void* p : ps)
+    if (p && !vg_aligned16(p)) return false;
+  return true;
+}
+
+}  // namespace
+
+#define VG_LAUNCH_VEC(kernel, vec4, total, st, ...)                                                          \
+  do {                                                                                                       \
+    if (vec4) {                                                                                              \
+      const size_t nvec__ = (total) / 4;                                                                     \
+      hipLaunchKernelGGL((kernel<4>), dim3(vg_stream_grid(nvec__, 256)), dim3(256), 0, st, __VA_ARGS__);     \
+    } else {                                                                                                 \
+      const size_t nvec__ = (total);                                                                         \
+      hipLaunchKernelGGL((kernel<1>), dim3(vg_stream_grid(nvec__, 256)), dim3(256), 0, st, __VA_ARGS__);     \
+    }                                                                                                        \
+  } while (0)
+
+extern "C" size_t vg_bn_workspace_bytes(int M, int C) {
+  if (M <= 0 || C <= 0) return 0;
+  return (size_t)5 * row_blocks(M) * C * sizeof(float) + (size_t)5 * C * sizeof(float);
+}
+
+extern "C" size_t vg_colsum_workspace_bytes(int M, int C) {
+  if (M <= 0 || C <= 0) return 0;
+  return (size_t)row_blocks(M) * C * sizeof(float);
+}
+
+extern "C" int vg_colsum(const float* x, float* out, int M, int C, void* ws, size_t ws_bytes, void* stream) {
+  VG_REQUIRE(x && out && M > 0 && C > 0, "vg_colsum: bad arguments");
+  SumF f{x};
+  return run_colreduce<1>("vg_colsum", f, M, C, all_aligned({x}), out, ws, ws_bytes, (hipStream_t)stream);
+}
+
+extern "C" int vg_bn_stats(const float* x, int M, int C, float eps, float momentum, float* mean, float* invstd,
+                           float* running_mean, float* running_var, void* ws, size_t ws_bytes, void* stream) {
+  VG_REQUIRE(x && mean && invstd && M > 0 && C > 0, "vg_bn_stats: bad arguments");
+  const size_t part = (size_t)2 * row_blocks(M) * C * sizeof(float);
+  const size_t need = part + (size_t)2 * C * sizeof(float);
+  if (!ws || ws_bytes < need) return vg_fail(VG_ERR_WORKSPACE, "vg_bn_stats: workspace of %zu bytes required, got %zu", need, ws_bytes);
+  float* sums = (float*)((char*)ws + part);
+  ShiftedMomentsF f{x};
+  hipStream_t st = (hipStream_t)stream;
+  if (int e = run_colreduce<2>("vg_bn_stats", f, M, C, all_aligned({x}), sums, ws, part, st)) return e;
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, st, x, (const float*)sums, M, C, eps, momentum,
+                     mean, invstd, running_mean, running_var);
+  VG_CHECK_LAUNCH("vg_bn_stats");
+  return VG_OK;
+}
+
+extern "C" int vg_bn_invstd_from_var(const float* var, float* invstd, int C, float eps, void* stream) {
+  VG_REQUIRE(var && invstd && C > 0, "vg_bn_invstd_from_var: bad arguments");
+  hipLaunchKernelGGL(invstd_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, var, invstd, C, eps);
+  VG_CHECK_LAUNCH("vg_bn_invstd_from_var");
+  return VG_OK;
+}
+
+extern "C" int vg_bn_apply(const float* x, const float* mean, const float* invstd, const float* gamma, const float* beta,
+                           float* y, int M, int C, int act, float slope, void* stream) {
+  VG_REQUIRE(x && mean && invstd && y && M > 0 && C > 0, "vg_bn_apply: bad arguments");
+  const bool v4 = C % 4 == 0 && all_aligned({x, mean, invstd, gamma, beta, y});
+  const size_t total = (size_t)M * C;
+  VG_LAUNCH_VEC(bn_apply_kernel, v4, total, (hipStream_t)stream, x, mean, invstd, gamma, beta, y, nvec__, C, act, slope);
+  VG_CHECK_LAUNCH("vg_bn_apply");
+  return VG_OK;
+}
+
+extern "C" int vg_bn_bwd_reduce(const float* gy, const float* x, const float* mean, const float* invstd, int M, int C,
+                                float* sums, void* ws, size_t ws_bytes, void* stream) {
+  VG_REQUIRE(gy && x && mean && invstd && sums && M > 0 && C > 0, "vg_bn_bwd_reduce: bad arguments");
+  BnBwdF f{gy, x, mean, invstd};
+  return run_colreduce<2>("vg_bn_bwd_reduce", f, M, C, all_aligned({gy, x, mean, invstd}), sums, ws, ws_bytes,
+                          (hipStream_t)stream);
+}
+
+extern "C" int vg_bn_bwd_apply(const float* gy, const float* x, const float* mean, const float* invstd, const float* gamma,
+                               const float* sums, float* gx, int M, int C, void* stream) {
+  VG_REQUIRE(gy && x && mean && invstd && sums && gx && M > 0 && C > 0, "vg_bn_bwd_apply: bad arguments");
+  const bool v4 = C % 4 == 0 && all_aligned({gy, x, mean, invstd, gamma, sums, gx});
+  const size_t total = (size_t)M * C;
+  const float inv_n = 1.0f / (float)M;
+  VG_LAUNCH_VEC(bn_bwd_apply_kernel, v4, total, (hipStream_t)stream, gy, x, mean, invstd, gamma, sums, gx, nvec__, C, inv_n);
+  VG_CHECK_LAUNCH("vg_bn_bwd_apply");
+  return VG_OK;
+}
+
+extern "C" int vg_bn_bwd_eval(const float* gy, const float* invstd, const float* gamma, float* gx, int M, int C,
+                              void* stream) {
+  VG_REQUIRE(gy && invstd && gx && M > 0 && C > 0, "vg_bn_bwd_eval: bad arguments");
+  const bool v4 = C % 4 == 0 && all_aligned({gy, invstd, gamma, gx});
+  const size_t total = (size_t)M * C;
+  VG_LAUNCH_VEC(bn_bwd_eval_kernel, v4, total, (hipStream_t)stream, gy, invstd, gamma, gx, nvec__, C);
+  VG_CHECK_LAUNCH("vg_bn_bwd_eval");
+  return VG_OK;
+}
+
+extern "C" int vg_bn_dbwd_reduce(const float* gy, const float* x, const float* u, const float* mean, const float* invstd,
+                                 int M, int C, float* sums5, void* ws, size_t ws_bytes, void* stream) {
+  VG_REQUIRE(gy && x && u && mean && invstd && sums5 && M > 0 && C > 0, "vg_bn_dbwd_reduce: bad arguments");
+  BnDbwdF f{gy, x, u, mean, invstd};
+  return run_colreduce<5>("vg_bn_dbwd_reduce", f, M, C, all_aligned({gy, x, u, mean, invstd}), sums5, ws, ws_bytes,
+                          (hipStream_t)stream);
+}
+
+extern "C" int vg_bn_dbwd_apply(const float* gy, const float* x, const float* u, const float* v, const float* w,
+                                const float* mean, const float* invstd, const float* gamma, const float* sums5, float* d_gy,
+                                float* d_x, float* d_gamma, int M, int C, void* stream) {
+  VG_REQUIRE(gy && x && u && mean && invstd && sums5 && d_gy && d_x && M > 0 && C > 0, "vg_bn_dbwd_apply: bad arguments");
+  const bool v4 = C % 4 == 0 && all_aligned({gy, x, u, v, w, mean, invstd, gamma, sums5, d_gy, d_x});
+  const size_t total = (size_t)M * C;
+  const float inv_n = 1.0f / (float)M;
+  hipStream_t st = (hipStream_t)stream;
+  VG_LAUNCH_VEC(bn_dbwd_apply_kernel, v4, total, st, gy, x, u, v, w, mean, invstd, gamma, sums5, d_gy, d_x, nvec__, C, inv_n);
+  VG_CHECK_LAUNCH("vg_bn_dbwd_apply");
+  if (d_gamma) {
+    hipLaunchKernelGGL(bn_dbwd_gamma_kernel, dim3((C + 255) / 256), dim3(256), 0, st, invstd, sums5, d_gamma, C, (float)M);
+    VG_CHECK_LAUNCH("vg_bn_dbwd_apply(gamma)");
+  }
+  return VG_OK;
+}
+
+extern "C" int vg_act_fwd(const float* x, float* y, size_t n, int act, float slope, void* stream) {
+  VG_REQUIRE(x && y && n > 0, "vg_act_fwd: bad arguments");
+  const bool v4 = n % 4 == 0 && all_aligned({x, y});
+  VG_LAUNCH_VEC(act_fwd_kernel, v4, n, (hipStream_t)stream, x, y, nvec__, act, slope);
+  VG_CHECK_LAUNCH("vg_act_fwd");
+  return VG_OK;
+}
+
+extern "C" int vg_act_bwd(const float* gy, const float* ref, float* gx, size_t n, int act, float slope, void* stream) {
+  VG_REQUIRE(gy && ref && gx && n > 0, "vg_act_bwd: bad arguments");
+  const bool v4 = n % 4 == 0 && all_aligned({gy, ref, gx});
+  VG_LAUNCH_VEC(act_bwd_kernel, v4, n, (hipStream_t)stream, gy, ref, gx, nvec__, act, slope);
+  VG_CHECK_LAUNCH("vg_act_bwd");
+  return VG_OK;
+}
+
+extern "C" int vg_act_dbwd_ref(const float* gg, const float* gy, const float* ref, float* d_ref, size_t n, int act,
+                               void* stream) {
+  VG_REQUIRE(gg && gy && ref && d_ref && n > 0, "vg_act_dbwd_ref: bad arguments");
+  VG_REQUIRE(act == VG_ACT_TANH || act == VG_ACT_SIGMOID, "vg_act_dbwd_ref: only tanh/sigmoid have a second derivative");
+  const bool v4 = n % 4 == 0 && all_aligned({gg, gy, ref, d_ref});
+  VG_LAUNCH_VEC(act_dbwd_ref_kernel, v4, n, (hipStream_t)stream, gg, gy, ref, d_ref, nvec__, act);
+  VG_CHECK_LAUNCH("vg_act_dbwd_ref");
+  return VG_OK;
+}
+
+extern "C" int vg_bcast_rows(const float* v, float* out, int M, int C, void* stream) {
+  VG_REQUIRE(v && out && M > 0 && C > 0, "vg_bcast_rows: bad arguments");
+  const bool v4 = C % 4 == 0 && all_aligned({v, out});
+  const size_t total = (size_t)M * C;
+  VG_LAUNCH_VEC(bcast_rows_kernel, v4, total, (hipStream_t)stream, v, out, nvec__, C);
+  VG_CHECK_LAUNCH("vg_bcast_rows");
+  return VG_OK;
+}

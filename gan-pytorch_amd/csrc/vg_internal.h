@@ -1,0 +1,54 @@
+// Internal helpers shared by the gfx950 kernel translation units of libvegans_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include "../../include/vegans_hip.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// Thread-local error text returned by vg_last_error().
+char* vg_error_buffer();
+int vg_fail(int code, const char* fmt, ...);
+
+#define VG_REQUIRE(cond, ...)                          \
+  do {                                                 \
+    if (!(cond)) return vg_fail(VG_ERR_INVALID, __VA_ARGS__); \
+  } while (0)
+
+// Checks the launch itself (not completion: the library never synchronises).
+#define VG_CHECK_LAUNCH(what)                                                        \
+  do {                                                                               \
+    hipError_t e__ = hipGetLastError();                                              \
+    if (e__ != hipSuccess)                                                           \
+      return vg_fail(VG_ERR_LAUNCH, "%s: launch failed: %s", what, hipGetErrorString(e__)); \
+  } while (0)
+
+static inline bool vg_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+// Memory-bound kernels: cap the grid and grid-stride the rest.
+static inline int vg_stream_grid(size_t work_items, int block) {
+  size_t blocks = (work_items + block - 1) / block;
+  if (blocks < 1) blocks = 1;
+  if (blocks > 2048) blocks = 2048;
+  return (int)blocks;
+}
+
+__device__ __forceinline__ float vg_wave_sum(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  return v;
+}
+
+// Block-wide sum for 256-thread blocks; result valid in thread 0. `red` holds >= 4 floats.
+__device__ __forceinline__ float vg_block_sum_256(float v, float* red) {
+  v = vg_wave_sum(v);
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) red[wid] = v;
+  __syncthreads();
+  float r = 0.f;
+  if (threadIdx.x == 0) r = (red[0] + red[1]) + (red[2] + red[3]);
+  return r;
+}

@@ -1,0 +1,163 @@
+"""ctypes binding of libvegans_hip.so (C ABI declared in include/vegans_hip.h).
+
+Every function here takes torch tensors that already live on the MI355X, checks dtype / device / contiguity
+on the host (a kernel that faults can take the whole GPU down), and enqueues the kernel on torch's current
+stream.  There is no CPU or stock-torch fallback: if the library is missing or the tensors are not on a GPU
+the call raises.
+"""
+import ctypes
+import os
+from ctypes import POINTER, Structure, c_float, c_int, c_int32, c_size_t, c_void_p
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libvegans_hip.so")
+
+ACT_NONE, ACT_RELU, ACT_LRELU, ACT_TANH, ACT_SIGMOID = 0, 1, 2, 3, 4
+
+
+class ConvGeom(Structure):
+    """Mirror of vg_conv_geom."""
+    _fields_ = [(n, c_int32) for n in ("N", "H", "W", "Ci", "Co", "kh", "kw", "Ho", "Wo", "sh", "sw", "ph", "pw")]
+
+
+class RmspropCfg(Structure):
+    _fields_ = [("lr", c_float), ("alpha", c_float), ("eps", c_float), ("weight_decay", c_float),
+                ("momentum", c_float), ("centered", c_int32), ("grad_scale", c_float),
+                ("clamp_lo", c_float), ("clamp_hi", c_float)]
+
+
+class AdamCfg(Structure):
+    _fields_ = [("lr", c_float), ("beta1", c_float), ("beta2", c_float), ("eps", c_float),
+                ("weight_decay", c_float), ("step_size", c_float), ("bias_correction2_sqrt", c_float),
+                ("amsgrad", c_int32), ("decoupled_wd", c_int32), ("grad_scale", c_float),
+                ("clamp_lo", c_float), ("clamp_hi", c_float)]
+
+
+class SgdCfg(Structure):
+    _fields_ = [("lr", c_float), ("momentum", c_float), ("dampening", c_float), ("weight_decay", c_float),
+                ("nesterov", c_int32), ("first_step", c_int32), ("grad_scale", c_float),
+                ("clamp_lo", c_float), ("clamp_hi", c_float)]
+
+
+_P = c_void_p  # device pointers and the stream travel as void*
+_G = POINTER(ConvGeom)
+
+# name -> (restype, argtypes); kept in one table so tests can compare it with the header.
+SIGNATURES = {
+    "vg_last_error": (ctypes.c_char_p, []),
+    "vg_abi_version": (c_int, []),
+    "vg_conv2d_fwd": (c_int, [_G, _P, _P, _P, _P, _P]),
+    "vg_conv2d_dgrad": (c_int, [_G, _P, _P, _P, _P, _P]),
+    "vg_conv2d_wgrad_workspace_bytes": (c_size_t, [_G]),
+    "vg_conv2d_wgrad": (c_int, [_G, _P, _P, _P, _P, c_size_t, _P]),
+    "vg_nchw_to_nhwc": (c_int, [_P, _P, c_int, c_int, c_int, _P]),
+    "vg_nhwc_to_nchw": (c_int, [_P, _P, c_int, c_int, c_int, _P]),
+    "vg_concat_channels": (c_int, [_P, c_int, c_int, _P, c_int, c_int, _P, c_int, c_int, _P]),
+    "vg_slice_channels": (c_int, [_P, c_int, c_int, c_int, _P, c_size_t, _P]),
+    "vg_colsum_workspace_bytes": (c_size_t, [c_int, c_int]),
+    "vg_colsum": (c_int, [_P, _P, c_int, c_int, _P, c_size_t, _P]),
+    "vg_bcast_rows": (c_int, [_P, _P, c_int, c_int, _P]),
+    "vg_add": (c_int, [_P, _P, _P, c_size_t, _P]),
+    "vg_scale": (c_int, [_P, c_float, _P, c_size_t, _P]),
+    "vg_fill": (c_int, [_P, c_float, c_size_t, _P]),
+    "vg_scalar_combine": (c_int, [_P, c_float, _P, c_float, _P, c_float, _P, _P, _P]),
+    "vg_bn_workspace_bytes": (c_size_t, [c_int, c_int]),
+    "vg_bn_stats": (c_int, [_P, c_int, c_int, c_float, c_float, _P, _P, _P, _P, _P, c_size_t, _P]),
+    "vg_bn_invstd_from_var": (c_int, [_P, _P, c_int, c_float, _P]),
+    "vg_bn_apply": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_float, _P]),
+    "vg_bn_bwd_reduce": (c_int, [_P, _P, _P, _P, c_int, c_int, _P, _P, c_size_t, _P]),
+    "vg_bn_bwd_apply": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, c_int, _P]),
+    "vg_bn_bwd_eval": (c_int, [_P, _P, _P, _P, c_int, c_int, _P]),
+    "vg_bn_dbwd_reduce": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, _P, _P, c_size_t, _P]),
+    "vg_bn_dbwd_apply": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, _P]),
+    "vg_act_fwd": (c_int, [_P, _P, c_size_t, c_int, c_float, _P]),
+    "vg_act_bwd": (c_int, [_P, _P, _P, c_size_t, c_int, c_float, _P]),
+    "vg_act_dbwd_ref": (c_int, [_P, _P, _P, _P, c_size_t, c_int, _P]),
+    "vg_reduce_workspace_bytes": (c_size_t, [c_size_t]),
+    "vg_loss_mean_fwd": (c_int, [_P, c_size_t, c_float, _P, _P, c_size_t, _P]),
+    "vg_loss_mean_bwd": (c_int, [_P, c_size_t, c_float, _P, _P]),
+    "vg_loss_bce_fwd": (c_int, [_P, _P, c_float, c_size_t, _P, _P, c_size_t, _P]),
+    "vg_loss_bce_bwd": (c_int, [_P, _P, _P, c_float, c_size_t, _P, _P]),
+    "vg_loss_mse_fwd": (c_int, [_P, _P, c_float, c_size_t, _P, _P, c_size_t, _P]),
+    "vg_loss_mse_bwd": (c_int, [_P, _P, _P, c_float, c_size_t, _P, _P]),
+    "vg_loss_l1_fwd": (c_int, [_P, _P, c_size_t, _P, _P, c_size_t, _P]),
+    "vg_loss_l1_bwd": (c_int, [_P, _P, _P, c_size_t, _P, _P, _P]),
+    "vg_gp_interp": (c_int, [_P, _P, _P, _P, c_int, c_size_t, _P]),
+    "vg_gp_rownorm": (c_int, [_P, _P, c_int, c_size_t, _P]),
+    "vg_gp_penalty_fwd": (c_int, [_P, c_int, _P, _P]),
+    "vg_gp_penalty_bwd": (c_int, [_P, _P, _P, _P, c_int, c_size_t, _P]),
+    "vg_rmsprop_step": (c_int, [_P, _P, _P, _P, _P, c_size_t, POINTER(RmspropCfg), _P]),
+    "vg_adam_step": (c_int, [_P, _P, _P, _P, _P, c_size_t, POINTER(AdamCfg), _P]),
+    "vg_sgd_step": (c_int, [_P, _P, _P, c_size_t, POINTER(SgdCfg), _P]),
+    "vg_clamp": (c_int, [_P, c_size_t, c_float, c_float, _P]),
+}
+
+_lib = None
+
+
+def load():
+    """Load the shared library once; raises if it has not been built (run `python __graft_entry__.py build`)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                "libvegans_hip.so not found at %s: build it with `make -C gan-pytorch_amd/csrc` "
+                "(this engine has no CPU or stock-kernel fallback)" % LIB_PATH)
+        lib = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+class HipError(RuntimeError):
+    pass
+
+
+def _check(rc, name):
+    if rc != 0:
+        raise HipError("%s failed (%d): %s" % (name, rc, load().vg_last_error().decode()))
+
+
+def _stream():
+    return c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t):
+    """Device pointer of a dense float32 GPU tensor (None -> null)."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise HipError("tensor is not on the GPU: this engine only runs on MI355X (device='cuda')")
+    if t.dtype != torch.float32:
+        raise HipError("tensor dtype %s: the kernels compute in float32" % t.dtype)
+    return c_void_p(t.data_ptr())
+
+
+def _dense(t):
+    """True if the tensor's memory is one gap-free block (any permutation of a contiguous layout)."""
+    return t.is_contiguous() or t.is_contiguous(memory_format=torch.channels_last) or t.numel() <= 1 or \
+        t.is_non_overlapping_and_dense()
+
+
+_workspace = {}
+
+
+def workspace(nbytes, device):
+    """Grow-only scratch buffer per device; all kernels of one rank run on one stream, so they can share it."""
+    key = device.index if device.index is not None else torch.cuda.current_device()
+    buf = _workspace.get(key)
+    if buf is None or buf.numel() < nbytes:
+        nbytes = max(int(nbytes), 1 << 20)
+        buf = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        _workspace[key] = buf
+    return buf
+
+
+def call(name, *args):
+    rc = getattr(load(), name)(*args)
+    _check(rc, name)

@@ -1,0 +1,160 @@
+"""Re-binding of the user's torch.nn layers to the HIP operators.
+
+The reference hands the user's `nn.Module` straight to torch (vegans/utils/networks.py:36-47).  Here every leaf
+layer of the network is switched, in place, to a subclass whose `forward` calls the engine operator while the
+module object, its `Parameter`s, buffers and `state_dict` keys stay exactly the same.  Containers and arbitrary
+user `forward()` code keep working because only leaves change.  A leaf layer type the engine has no kernel for
+raises at construction time instead of silently running a stock kernel.
+"""
+import torch
+from torch import nn
+
+from . import ops
+from .. import _hip
+
+
+def _pair(v):
+    return (v, v) if isinstance(v, int) else tuple(v)
+
+
+class HipConv2d(nn.Conv2d):
+    def forward(self, x):
+        return ops.conv2d(x, self.weight, self.bias, _pair(self.stride), _pair(self.padding))
+
+
+class HipConvTranspose2d(nn.ConvTranspose2d):
+    def forward(self, x, output_size=None):
+        if output_size is not None:
+            raise NotImplementedError("ConvTranspose2d(output_size=...) is not supported by the HIP engine")
+        return ops.conv_transpose2d(x, self.weight, self.bias, _pair(self.stride), _pair(self.padding),
+                                    _pair(self.output_padding))
+
+
+class HipLinear(nn.Linear):
+    def forward(self, x):
+        return ops.linear(x, self.weight, self.bias)
+
+
+class _HipBatchNorm:
+    def _hip_forward(self, x):
+        # same bookkeeping as torch.nn.modules.batchnorm._BatchNorm.forward
+        if self.momentum is None:
+            factor = 0.0
+        else:
+            factor = self.momentum
+        if self.training and self.track_running_stats and self.num_batches_tracked is not None:
+            self.num_batches_tracked.add_(1)
+            if self.momentum is None:
+                factor = 1.0 / float(self.num_batches_tracked)
+        use_batch_stats = self.training or (self.running_mean is None and self.running_var is None)
+        rm = self.running_mean if (not self.training or self.track_running_stats) else None
+        rv = self.running_var if (not self.training or self.track_running_stats) else None
+        return ops.batch_norm(x, self.weight, self.bias, rm, rv, use_batch_stats, factor, self.eps)
+
+
+class HipBatchNorm2d(nn.BatchNorm2d, _HipBatchNorm):
+    def forward(self, x):
+        if x.dim() != 4:
+            raise ValueError("expected 4D input (got {}D input)".format(x.dim()))
+        return self._hip_forward(x)
+
+
+class HipBatchNorm1d(nn.BatchNorm1d, _HipBatchNorm):
+    def forward(self, x):
+        if x.dim() != 2:
+            raise NotImplementedError("BatchNorm1d on %d-d input is not supported by the HIP engine" % x.dim())
+        return self._hip_forward(x)
+
+
+class HipReLU(nn.ReLU):
+    def forward(self, x):
+        return ops.activation(x, _hip.ACT_RELU)
+
+
+class HipLeakyReLU(nn.LeakyReLU):
+    def forward(self, x):
+        return ops.activation(x, _hip.ACT_LRELU, self.negative_slope)
+
+
+class HipTanh(nn.Tanh):
+    def forward(self, x):
+        return ops.activation(x, _hip.ACT_TANH)
+
+
+class HipSigmoid(nn.Sigmoid):
+    def forward(self, x):
+        return ops.activation(x, _hip.ACT_SIGMOID)
+
+
+class HipFlatten(nn.Flatten):
+    def forward(self, x):
+        if self.start_dim != 1 or self.end_dim not in (-1, x.dim() - 1):
+            raise NotImplementedError("only Flatten(start_dim=1, end_dim=-1) is supported by the HIP engine")
+        return ops.flatten(x)
+
+
+_SWAP = {
+    nn.Conv2d: HipConv2d,
+    nn.ConvTranspose2d: HipConvTranspose2d,
+    nn.Linear: HipLinear,
+    nn.BatchNorm2d: HipBatchNorm2d,
+    nn.BatchNorm1d: HipBatchNorm1d,
+    nn.ReLU: HipReLU,
+    nn.LeakyReLU: HipLeakyReLU,
+    nn.Tanh: HipTanh,
+    nn.Sigmoid: HipSigmoid,
+    nn.Flatten: HipFlatten,
+}
+_STOCK = {v: k for k, v in _SWAP.items()}
+
+# leaves that launch no kernel (pure metadata / identity)
+_PASS_THROUGH = (nn.Identity, nn.Unflatten)
+
+
+def _validate(m):
+    if isinstance(m, (nn.Conv2d, nn.ConvTranspose2d)):
+        if _pair(m.dilation) != (1, 1) or m.groups != 1:
+            raise NotImplementedError("%s with dilation/groups is not supported by the HIP engine" % type(m).__name__)
+        if isinstance(m.padding, str) or m.padding_mode != "zeros":
+            raise NotImplementedError("%s padding=%r/%s is not supported by the HIP engine" %
+                                      (type(m).__name__, m.padding, m.padding_mode))
+
+
+def bind(network):
+    """Switch every supported leaf of `network` to its HIP subclass (idempotent). Returns the network."""
+    from ..utils.layers import LayerReshape, LayerPrintSize
+    for m in network.modules():
+        t = type(m)
+        if t in _STOCK:
+            continue
+        if t in _SWAP:
+            _validate(m)
+            m.__class__ = _SWAP[t]
+            continue
+        if isinstance(m, _PASS_THROUGH) or isinstance(m, (LayerReshape, LayerPrintSize)):
+            continue
+        if len(list(m.children())) == 0 and len(list(m.parameters(recurse=False))) + len(list(m.buffers(recurse=False))) >= 0:
+            if t.__module__.startswith("torch.nn.modules"):
+                raise NotImplementedError(
+                    "layer %s has no MI355X kernel in this engine (supported: %s)" %
+                    (t.__name__, ", ".join(sorted(k.__name__ for k in _SWAP))))
+    return network
+
+
+def unbind(network):
+    """Give the user their stock torch classes back (parameters are untouched)."""
+    for m in network.modules():
+        if type(m) in _STOCK:
+            m.__class__ = _STOCK[type(m)]
+    return network
+
+
+def prepare_parameters(network):
+    """Store 4-d weights as [Co][kh][kw][Ci] (channels_last) so kernels read them without a per-call re-layout.
+    Logical values, shapes and state_dict contents are unchanged."""
+    for p in network.parameters():
+        if p.dim() == 4 and not p.data.is_contiguous(memory_format=torch.channels_last):
+            p.data = ops.to_nhwc(p.data)
+            if p.grad is not None:
+                p.grad = None
+    return network

@@ -1,0 +1,777 @@
+"""Differentiable operators of the training step, each a thin `torch.autograd.Function` over the HIP kernels.
+
+torch's autograd engine only sequences these nodes (it is plumbing); every tensor value is produced by a
+kernel of libvegans_hip.so.  Backward passes are themselves written with the Functions below, so
+`create_graph=True` (the gradient penalty of WassersteinGANGP.py:67-82 in the reference) differentiates through
+them a second time:
+
+    conv_fwd(x, w)  --backward-->  conv_dgrad(gy, w), conv_wgrad(gy, x)
+    conv_dgrad(gy, w) --backward--> conv_fwd(ggx, w), conv_wgrad(gy, ggx)
+    conv_wgrad(gy, x) --backward--> conv_fwd(x, ggw),  conv_dgrad(gy, ggw)
+
+Memory layout: 4-d activations are NCHW-shaped tensors with channels_last strides (NHWC in memory); 4-d weights
+are kept channels_last as well ([Co][kh][kw][Ci] in memory).  Tensors that arrive in another layout are
+re-laid-out by the layout kernels, never by torch.
+"""
+import ctypes
+from ctypes import c_float, c_int, c_size_t
+
+import torch
+from torch.autograd import Function
+from torch.autograd.function import once_differentiable
+
+from .. import _hip
+from .._hip import ConvGeom, _ptr, _stream, call, workspace
+
+CL = torch.channels_last
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# layout helpers (not differentiable by themselves: a layout change is the identity on the logical tensor)
+# ----------------------------------------------------------------------------------------------------------------
+def _require_gpu(t):
+    if not t.is_cuda:
+        raise _hip.HipError("input tensor is on %s: the engine only runs on the GPU" % t.device)
+    if t.dtype != torch.float32:
+        raise _hip.HipError("input tensor is %s: the engine computes in float32" % t.dtype)
+
+
+def to_nhwc(t):
+    """Return `t` (N,C,H,W) with NHWC memory; no copy when it already is."""
+    _require_gpu(t)
+    if t.dim() != 4:
+        return t if t.is_contiguous() else _plain_contiguous(t)
+    if t.is_contiguous(memory_format=CL):
+        return t
+    if not t.is_contiguous():
+        t = _plain_contiguous(t)
+    n, c, h, w = t.shape
+    out = torch.empty((n, c, h, w), dtype=t.dtype, device=t.device, memory_format=CL)
+    call("vg_nchw_to_nhwc", _ptr(t), _ptr(out), n, c, h * w, _stream())
+    return out
+
+
+def to_nchw(t):
+    """Return `t` (N,C,H,W) with plain contiguous NCHW memory."""
+    _require_gpu(t)
+    if t.dim() != 4 or t.is_contiguous():
+        return t if t.is_contiguous() else _plain_contiguous(t)
+    if not t.is_contiguous(memory_format=CL):
+        return _plain_contiguous(t)
+    n, c, h, w = t.shape
+    out = torch.empty((n, c, h, w), dtype=t.dtype, device=t.device)
+    call("vg_nhwc_to_nchw", _ptr(t), _ptr(out), n, c, h * w, _stream())
+    return out
+
+
+def _plain_contiguous(t):
+    # Exotic strides (slices, expands) do not occur on the training path; refuse instead of silently running a
+    # stock copy kernel.
+    raise _hip.HipError("tensor with strides %s (shape %s) is neither NCHW- nor NHWC-contiguous" %
+                        (tuple(t.stride()), tuple(t.shape)))
+
+
+def _new_act(n, c, h, w, like, flat):
+    if flat:
+        return torch.empty((n, c), dtype=torch.float32, device=like.device)
+    return torch.empty((n, c, h, w), dtype=torch.float32, device=like.device, memory_format=CL)
+
+
+def _weight_mem(w):
+    """Weight memory must be [Co][kh][kw][Ci]: channels_last for 4-d, contiguous for 2-d."""
+    if w.dim() == 4:
+        return to_nhwc(w)
+    return w if w.is_contiguous() else _plain_contiguous(w)
+
+
+class Geom:
+    """Convolution geometry + the ctypes struct handed to the library. `flat` marks Linear layers (2-d tensors)."""
+    __slots__ = ("c", "flat", "N", "H", "W", "Ci", "Co", "kh", "kw", "Ho", "Wo", "sh", "sw", "ph", "pw")
+
+    def __init__(self, N, H, W, Ci, Co, kh, kw, sh, sw, ph, pw, flat=False):
+        Ho = (H + 2 * ph - kh) // sh + 1
+        Wo = (W + 2 * pw - kw) // sw + 1
+        if Ho <= 0 or Wo <= 0:
+            raise ValueError("convolution output would be empty: H=%d W=%d k=(%d,%d) s=(%d,%d) p=(%d,%d)" %
+                             (H, W, kh, kw, sh, sw, ph, pw))
+        self.N, self.H, self.W, self.Ci, self.Co = N, H, W, Ci, Co
+        self.kh, self.kw, self.Ho, self.Wo = kh, kw, Ho, Wo
+        self.sh, self.sw, self.ph, self.pw = sh, sw, ph, pw
+        self.flat = flat
+        self.c = ConvGeom(N, H, W, Ci, Co, kh, kw, Ho, Wo, sh, sw, ph, pw)
+
+    def x_shape(self):
+        return (self.N, self.Ci) if self.flat else (self.N, self.Ci, self.H, self.W)
+
+    def y_shape(self):
+        return (self.N, self.Co) if self.flat else (self.N, self.Co, self.Ho, self.Wo)
+
+    def w_numel(self):
+        return self.Co * self.kh * self.kw * self.Ci
+
+
+def _check_shape(t, shape, what):
+    if tuple(t.shape) != tuple(shape):
+        raise _hip.HipError("%s has shape %s, geometry expects %s" % (what, tuple(t.shape), tuple(shape)))
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# raw kernels (no autograd)
+# ----------------------------------------------------------------------------------------------------------------
+def raw_conv_fwd(g, x, w, bias):
+    x, w = to_nhwc(x), _weight_mem(w)
+    _check_shape(x, g.x_shape(), "conv input")
+    if w.numel() != g.w_numel():
+        raise _hip.HipError("weight has %d elements, geometry expects %d" % (w.numel(), g.w_numel()))
+    y = _new_act(g.N, g.Co, g.Ho, g.Wo, x, g.flat)
+    call("vg_conv2d_fwd", ctypes.byref(g.c), _ptr(x), _ptr(w), _ptr(bias), _ptr(y), _stream())
+    return y
+
+
+def raw_conv_dgrad(g, gy, w, bias):
+    gy, w = to_nhwc(gy), _weight_mem(w)
+    _check_shape(gy, g.y_shape(), "conv output-side tensor")
+    if w.numel() != g.w_numel():
+        raise _hip.HipError("weight has %d elements, geometry expects %d" % (w.numel(), g.w_numel()))
+    gx = _new_act(g.N, g.Ci, g.H, g.W, gy, g.flat)
+    call("vg_conv2d_dgrad", ctypes.byref(g.c), _ptr(gy), _ptr(w), _ptr(bias), _ptr(gx), _stream())
+    return gx
+
+
+def raw_conv_wgrad(g, gy, x, w_shape):
+    gy, x = to_nhwc(gy), to_nhwc(x)
+    _check_shape(gy, g.y_shape(), "conv output-side tensor")
+    _check_shape(x, g.x_shape(), "conv input")
+    if len(w_shape) == 4:
+        gw = torch.empty(w_shape, dtype=torch.float32, device=x.device, memory_format=CL)
+    else:
+        gw = torch.empty(w_shape, dtype=torch.float32, device=x.device)
+    if gw.numel() != g.w_numel():
+        raise _hip.HipError("weight gradient shape %s does not match the geometry" % (tuple(w_shape),))
+    nbytes = _hip.load().vg_conv2d_wgrad_workspace_bytes(ctypes.byref(g.c))
+    ws = workspace(nbytes, x.device) if nbytes else None
+    call("vg_conv2d_wgrad", ctypes.byref(g.c), _ptr(gy), _ptr(x), _ptr(gw),
+         ctypes.c_void_p(ws.data_ptr()) if ws is not None else None, c_size_t(nbytes), _stream())
+    return gw
+
+
+def _rows_cols(t):
+    """View an activation as [M][C] (C = channel / feature dim, innermost in memory)."""
+    if t.dim() == 4:
+        n, c, h, w = t.shape
+        return n * h * w, c
+    if t.dim() == 2:
+        return t.shape[0], t.shape[1]
+    raise _hip.HipError("activation must be 2-d or 4-d, got %d-d" % t.dim())
+
+
+def raw_colsum(x):
+    x = to_nhwc(x)
+    m, c = _rows_cols(x)
+    out = torch.empty(c, dtype=torch.float32, device=x.device)
+    nbytes = _hip.load().vg_colsum_workspace_bytes(m, c)
+    ws = workspace(nbytes, x.device)
+    call("vg_colsum", _ptr(x), _ptr(out), m, c, ctypes.c_void_p(ws.data_ptr()), c_size_t(nbytes), _stream())
+    return out
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# convolution family
+# ----------------------------------------------------------------------------------------------------------------
+class ConvFwdFn(Function):
+    @staticmethod
+    def forward(ctx, x, w, bias, g):
+        # the tensors are saved as given (not their re-laid-out copies) so second-order graphs stay connected
+        ctx.g = g
+        ctx.save_for_backward(x, w)
+        ctx.has_bias = bias is not None
+        return raw_conv_fwd(g, x, w, bias)
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w = ctx.saved_tensors
+        g = ctx.g
+        gx = ConvDgradFn.apply(gy, w, None, g) if ctx.needs_input_grad[0] else None
+        gw = ConvWgradFn.apply(gy, x, g, tuple(w.shape)) if ctx.needs_input_grad[1] else None
+        gb = ColSumFn.apply(gy) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
+        return gx, gw, gb, None
+
+
+class ConvDgradFn(Function):
+    """gx = conv_transpose(gy, w) (+bias over the Ci channels): also the forward of ConvTranspose2d."""
+
+    @staticmethod
+    def forward(ctx, gy, w, bias, g):
+        ctx.g = g
+        ctx.save_for_backward(gy, w)
+        ctx.has_bias = bias is not None
+        return raw_conv_dgrad(g, gy, w, bias)
+
+    @staticmethod
+    def backward(ctx, ggx):
+        gy, w = ctx.saved_tensors
+        g = ctx.g
+        d_gy = ConvFwdFn.apply(ggx, w, None, g) if ctx.needs_input_grad[0] else None
+        d_w = ConvWgradFn.apply(gy, ggx, g, tuple(w.shape)) if ctx.needs_input_grad[1] else None
+        d_b = ColSumFn.apply(ggx) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
+        return d_gy, d_w, d_b, None
+
+
+class ConvWgradFn(Function):
+    @staticmethod
+    def forward(ctx, gy, x, g, w_shape):
+        ctx.g = g
+        ctx.save_for_backward(gy, x)
+        return raw_conv_wgrad(g, gy, x, w_shape)
+
+    @staticmethod
+    def backward(ctx, ggw):
+        gy, x = ctx.saved_tensors
+        g = ctx.g
+        d_gy = ConvFwdFn.apply(x, ggw, None, g) if ctx.needs_input_grad[0] else None
+        d_x = ConvDgradFn.apply(gy, ggw, None, g) if ctx.needs_input_grad[1] else None
+        return d_gy, d_x, None, None
+
+
+class ColSumFn(Function):
+    """out[c] = sum over rows of x[m][c] (bias gradient)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        ctx.shape = tuple(x.shape)
+        return raw_colsum(x)
+
+    @staticmethod
+    def backward(ctx, gout):
+        shape = ctx.shape
+        like = gout
+        if len(shape) == 4:
+            out = torch.empty(shape, dtype=torch.float32, device=like.device, memory_format=CL)
+            m, c = shape[0] * shape[2] * shape[3], shape[1]
+        else:
+            out = torch.empty(shape, dtype=torch.float32, device=like.device)
+            m, c = shape
+        call("vg_bcast_rows", _ptr(gout.contiguous()), _ptr(out), m, c, _stream())
+        return out
+
+
+def conv2d(x, w, bias, stride, padding):
+    n, ci, h, wd = x.shape
+    co, ci_w, kh, kw = w.shape
+    if ci_w != ci:
+        raise _hip.HipError("Conv2d: input has %d channels, weight expects %d" % (ci, ci_w))
+    g = Geom(n, h, wd, ci, co, kh, kw, stride[0], stride[1], padding[0], padding[1])
+    return ConvFwdFn.apply(x, w, bias, g)
+
+
+def conv_transpose2d(x, w, bias, stride, padding, output_padding=(0, 0)):
+    """ConvTranspose2d forward = input-gradient of the convolution whose weight is `w` ([Cin, Cout, kh, kw])."""
+    n, cin, hi, wi = x.shape
+    cin_w, cout, kh, kw = w.shape
+    if cin_w != cin:
+        raise _hip.HipError("ConvTranspose2d: input has %d channels, weight expects %d" % (cin, cin_w))
+    h = (hi - 1) * stride[0] - 2 * padding[0] + kh + output_padding[0]
+    wd = (wi - 1) * stride[1] - 2 * padding[1] + kw + output_padding[1]
+    g = Geom(n, h, wd, cout, cin, kh, kw, stride[0], stride[1], padding[0], padding[1])
+    if (g.Ho, g.Wo) != (hi, wi):
+        raise _hip.HipError("ConvTranspose2d geometry is not invertible for this output_padding")
+    return ConvDgradFn.apply(x, w, bias, g)
+
+
+def linear(x, w, bias):
+    if x.dim() != 2:
+        raise _hip.HipError("Linear expects a 2-d input [batch, features], got shape %s" % (tuple(x.shape),))
+    n, ci = x.shape
+    co, ci_w = w.shape
+    if ci_w != ci:
+        raise _hip.HipError("Linear: input has %d features, weight expects %d" % (ci, ci_w))
+    g = Geom(n, 1, 1, ci, co, 1, 1, 1, 1, 0, 0, flat=True)
+    return ConvFwdFn.apply(x, w, bias, g)
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# batch norm
+# ----------------------------------------------------------------------------------------------------------------
+def _bn_ws(m, c, device):
+    nbytes = _hip.load().vg_bn_workspace_bytes(m, c)
+    return workspace(nbytes, device), nbytes
+
+
+class BatchNormTrainFn(Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, running_mean, running_var, momentum, eps):
+        x_in = x
+        x = to_nhwc(x)
+        m, c = _rows_cols(x)
+        mean = torch.empty(c, dtype=torch.float32, device=x.device)
+        invstd = torch.empty(c, dtype=torch.float32, device=x.device)
+        ws, nbytes = _bn_ws(m, c, x.device)
+        call("vg_bn_stats", _ptr(x), m, c, c_float(eps), c_float(momentum), _ptr(mean), _ptr(invstd),
+             _ptr(running_mean), _ptr(running_var), ctypes.c_void_p(ws.data_ptr()), c_size_t(nbytes), _stream())
+        y = torch.empty_like(x)
+        call("vg_bn_apply", _ptr(x), _ptr(mean), _ptr(invstd), _ptr(gamma), _ptr(beta), _ptr(y), m, c,
+             _hip.ACT_NONE, c_float(0.0), _stream())
+        ctx.save_for_backward(x_in, gamma, mean, invstd)
+        ctx.has_affine = (gamma is not None, beta is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, gamma, mean, invstd = ctx.saved_tensors
+        gx, ggamma, gbeta = BatchNormBwdFn.apply(gy, x, gamma, mean, invstd)
+        return (gx, ggamma if ctx.has_affine[0] else None, gbeta if ctx.has_affine[1] else None,
+                None, None, None, None)
+
+
+class BatchNormBwdFn(Function):
+    """(gx, ggamma, gbeta) of training-mode batch norm as a function of (gy, x, gamma); mean/invstd are the batch
+    statistics of x (their dependence on x is part of the second derivative below)."""
+
+    @staticmethod
+    def forward(ctx, gy, x, gamma, mean, invstd):
+        ctx.save_for_backward(gy, x, gamma, mean, invstd)
+        gy, x = to_nhwc(gy), to_nhwc(x)
+        m, c = _rows_cols(x)
+        sums = torch.empty((2, c), dtype=torch.float32, device=x.device)
+        ws, nbytes = _bn_ws(m, c, x.device)
+        call("vg_bn_bwd_reduce", _ptr(gy), _ptr(x), _ptr(mean), _ptr(invstd), m, c, _ptr(sums),
+             ctypes.c_void_p(ws.data_ptr()), c_size_t(nbytes), _stream())
+        gx = torch.empty_like(x)
+        call("vg_bn_bwd_apply", _ptr(gy), _ptr(x), _ptr(mean), _ptr(invstd), _ptr(gamma), _ptr(sums), _ptr(gx), m, c,
+             _stream())
+        ctx.set_materialize_grads(False)
+        return gx, sums[1], sums[0]
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, u, v, w):
+        gy, x, gamma, mean, invstd = ctx.saved_tensors
+        gy, x = to_nhwc(gy), to_nhwc(x)
+        m, c = _rows_cols(x)
+        if u is None:
+            u = torch.empty_like(x)
+            call("vg_fill", _ptr(u), c_float(0.0), c_size_t(u.numel()), _stream())
+        u = to_nhwc(u)
+        v = v.contiguous() if v is not None else None
+        w = w.contiguous() if w is not None else None
+        sums5 = torch.empty((5, c), dtype=torch.float32, device=x.device)
+        ws, nbytes = _bn_ws(m, c, x.device)
+        call("vg_bn_dbwd_reduce", _ptr(gy), _ptr(x), _ptr(u), _ptr(mean), _ptr(invstd), m, c, _ptr(sums5),
+             ctypes.c_void_p(ws.data_ptr()), c_size_t(nbytes), _stream())
+        d_gy = torch.empty_like(x)
+        d_x = torch.empty_like(x)
+        d_gamma = torch.empty(c, dtype=torch.float32, device=x.device) if gamma is not None else None
+        call("vg_bn_dbwd_apply", _ptr(gy), _ptr(x), _ptr(u), _ptr(v), _ptr(w), _ptr(mean), _ptr(invstd), _ptr(gamma),
+             _ptr(sums5), _ptr(d_gy), _ptr(d_x), _ptr(d_gamma), m, c, _stream())
+        return d_gy, d_x, d_gamma, None, None
+
+
+class BatchNormEvalFn(Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, running_mean, running_var, eps):
+        x = to_nhwc(x)
+        m, c = _rows_cols(x)
+        invstd = torch.empty(c, dtype=torch.float32, device=x.device)
+        call("vg_bn_invstd_from_var", _ptr(running_var), _ptr(invstd), c, c_float(eps), _stream())
+        y = torch.empty_like(x)
+        call("vg_bn_apply", _ptr(x), _ptr(running_mean), _ptr(invstd), _ptr(gamma), _ptr(beta), _ptr(y), m, c,
+             _hip.ACT_NONE, c_float(0.0), _stream())
+        ctx.save_for_backward(x, gamma, running_mean, invstd)
+        ctx.has_affine = (gamma is not None, beta is not None)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gy):
+        x, gamma, mean, invstd = ctx.saved_tensors
+        gy = to_nhwc(gy)
+        m, c = _rows_cols(x)
+        gx = torch.empty_like(x)
+        call("vg_bn_bwd_eval", _ptr(gy), _ptr(invstd), _ptr(gamma), _ptr(gx), m, c, _stream())
+        ggamma = gbeta = None
+        if ctx.has_affine[0] or ctx.has_affine[1]:
+            sums = torch.empty((2, c), dtype=torch.float32, device=x.device)
+            ws, nbytes = _bn_ws(m, c, x.device)
+            call("vg_bn_bwd_reduce", _ptr(gy), _ptr(x), _ptr(mean), _ptr(invstd), m, c, _ptr(sums),
+                 ctypes.c_void_p(ws.data_ptr()), c_size_t(nbytes), _stream())
+            ggamma = sums[1] if ctx.has_affine[0] else None
+            gbeta = sums[0] if ctx.has_affine[1] else None
+        return gx, ggamma, gbeta, None, None, None
+
+
+def batch_norm(x, gamma, beta, running_mean, running_var, training, momentum, eps):
+    if training:
+        return BatchNormTrainFn.apply(x, gamma, beta, running_mean, running_var, momentum, eps)
+    return BatchNormEvalFn.apply(x, gamma, beta, running_mean, running_var, eps)
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# activations
+# ----------------------------------------------------------------------------------------------------------------
+_SAVES_OUTPUT = (_hip.ACT_TANH, _hip.ACT_SIGMOID)
+
+
+def _dense_like(t):
+    if t.dim() == 4:
+        return to_nhwc(t)
+    return t if t.is_contiguous() else _plain_contiguous(t)
+
+
+class ActFn(Function):
+    @staticmethod
+    def forward(ctx, x, act, slope):
+        x_in = x
+        x = _dense_like(x)
+        y = torch.empty_like(x)
+        call("vg_act_fwd", _ptr(x), _ptr(y), c_size_t(x.numel()), act, c_float(slope), _stream())
+        ctx.act, ctx.slope = act, slope
+        ctx.save_for_backward(y if act in _SAVES_OUTPUT else x_in)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        (ref,) = ctx.saved_tensors
+        return ActBwdFn.apply(gy, ref, ctx.act, ctx.slope), None, None
+
+
+class ActBwdFn(Function):
+    """gx = gy * act'(ref); ref is the forward input (relu, leaky relu) or output (tanh, sigmoid)."""
+
+    @staticmethod
+    def forward(ctx, gy, ref, act, slope):
+        ctx.act, ctx.slope = act, slope
+        ctx.save_for_backward(gy, ref)
+        ref = _dense_like(ref)
+        gy = _match_layout(_dense_like(gy), ref)
+        gx = torch.empty_like(ref)
+        call("vg_act_bwd", _ptr(gy), _ptr(ref), _ptr(gx), c_size_t(ref.numel()), act, c_float(slope), _stream())
+        return gx
+
+    @staticmethod
+    def backward(ctx, gg):
+        gy, ref = ctx.saved_tensors
+        d_gy = ActBwdFn.apply(gg, ref, ctx.act, ctx.slope) if ctx.needs_input_grad[0] else None
+        d_ref = None
+        if ctx.act in _SAVES_OUTPUT and ctx.needs_input_grad[1]:
+            if torch.is_grad_enabled():
+                raise NotImplementedError("third-order derivatives of tanh/sigmoid are not implemented")
+            ref_ = _dense_like(ref)
+            gg_ = _match_layout(_dense_like(gg), ref_)
+            gy_ = _match_layout(_dense_like(gy), ref_)
+            d_ref = torch.empty_like(ref_)
+            call("vg_act_dbwd_ref", _ptr(gg_), _ptr(gy_), _ptr(ref_), _ptr(d_ref), c_size_t(ref_.numel()), ctx.act,
+                 _stream())
+        return d_gy, d_ref, None, None
+
+
+def _match_layout(t, ref):
+    """Elementwise kernels index flat memory, so both operands must share one memory order."""
+    if t.stride() == ref.stride():
+        return t
+    if ref.dim() == 4:
+        return to_nhwc(t) if ref.is_contiguous(memory_format=CL) else to_nchw(t)
+    return t
+
+
+def activation(x, act, slope=0.0):
+    return ActFn.apply(x, act, float(slope))
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# losses (scalars stay on the device)
+# ----------------------------------------------------------------------------------------------------------------
+def _reduce_ws(n, device):
+    nbytes = _hip.load().vg_reduce_workspace_bytes(c_size_t(n))
+    return workspace(nbytes, device), nbytes
+
+
+def _flat_dense(t):
+    _require_gpu(t)
+    if not (t.is_contiguous() or t.is_contiguous(memory_format=CL)):
+        _plain_contiguous(t)
+    return t
+
+
+class MeanLossFn(Function):
+    """sign * mean(pred): the Wasserstein loss with the sign fixed by the call site (ones -> -1, zeros -> +1)."""
+
+    @staticmethod
+    def forward(ctx, pred, sign):
+        pred = _flat_dense(pred)
+        n = pred.numel()
+        out = torch.empty((), dtype=torch.float32, device=pred.device)
+        ws, nbytes = _reduce_ws(n, pred.device)
+        call("vg_loss_mean_fwd", _ptr(pred), c_size_t(n), c_float(sign), _ptr(out), ctypes.c_void_p(ws.data_ptr()),
+             c_size_t(nbytes), _stream())
+        ctx.sign = sign
+        ctx.like = pred
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gout):
+        pred = ctx.like
+        d = torch.empty_like(pred)
+        call("vg_loss_mean_bwd", _ptr(gout), c_size_t(pred.numel()), c_float(ctx.sign), _ptr(d), _stream())
+        return d, None
+
+
+class PointLossFn(Function):
+    """BCE ('bce') or least squares ('mse') against a constant target or a target tensor."""
+
+    @staticmethod
+    def forward(ctx, pred, target, tconst, kind):
+        pred = _flat_dense(pred)
+        if target is not None:
+            target = _match_layout(_flat_dense(target), pred)
+        n = pred.numel()
+        out = torch.empty((), dtype=torch.float32, device=pred.device)
+        ws, nbytes = _reduce_ws(n, pred.device)
+        call("vg_loss_%s_fwd" % kind, _ptr(pred), _ptr(target), c_float(tconst), c_size_t(n), _ptr(out),
+             ctypes.c_void_p(ws.data_ptr()), c_size_t(nbytes), _stream())
+        ctx.kind, ctx.tconst = kind, tconst
+        ctx.save_for_backward(pred, target)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gout):
+        pred, target = ctx.saved_tensors
+        d = torch.empty_like(pred)
+        call("vg_loss_%s_bwd" % ctx.kind, _ptr(gout), _ptr(pred), _ptr(target), c_float(ctx.tconst),
+             c_size_t(pred.numel()), _ptr(d), _stream())
+        return d, None, None, None
+
+
+class L1LossFn(Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        a = _flat_dense(a)
+        b = _match_layout(_flat_dense(b), a)
+        if a.shape != b.shape:
+            raise _hip.HipError("L1 loss operands differ in shape: %s vs %s" % (tuple(a.shape), tuple(b.shape)))
+        n = a.numel()
+        out = torch.empty((), dtype=torch.float32, device=a.device)
+        ws, nbytes = _reduce_ws(n, a.device)
+        call("vg_loss_l1_fwd", _ptr(a), _ptr(b), c_size_t(n), _ptr(out), ctypes.c_void_p(ws.data_ptr()),
+             c_size_t(nbytes), _stream())
+        ctx.save_for_backward(a, b)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gout):
+        a, b = ctx.saved_tensors
+        da = torch.empty_like(a) if ctx.needs_input_grad[0] else None
+        db = torch.empty_like(b) if ctx.needs_input_grad[1] else None
+        if da is None and db is None:
+            return None, None
+        call("vg_loss_l1_bwd", _ptr(gout), _ptr(a), _ptr(b), c_size_t(a.numel()), _ptr(da), _ptr(db), _stream())
+        return da, db
+
+
+class CombineFn(Function):
+    """out = c0*a + c1*b + c2*c on device scalars (b, c optional); second output b/a is logged only."""
+
+    @staticmethod
+    def forward(ctx, a, b, c, c0, c1, c2, want_ratio):
+        out = torch.empty((), dtype=torch.float32, device=a.device)
+        ratio = torch.empty((), dtype=torch.float32, device=a.device) if want_ratio else None
+        call("vg_scalar_combine", _ptr(a), c_float(c0), _ptr(b), c_float(c1), _ptr(c), c_float(c2), _ptr(out),
+             _ptr(ratio), _stream())
+        ctx.coefs = (c0, c1, c2)
+        ctx.present = (True, b is not None, c is not None)
+        ctx.set_materialize_grads(False)
+        if want_ratio:
+            ctx.mark_non_differentiable(ratio)
+            return out, ratio
+        return out, None
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gout, _gratio):
+        if gout is None:
+            return (None,) * 7
+        grads = []
+        for coef, present, need in zip(ctx.coefs, ctx.present, ctx.needs_input_grad[:3]):
+            if present and need:
+                g = torch.empty_like(gout)
+                call("vg_scale", _ptr(gout), c_float(coef), _ptr(g), c_size_t(1), _stream())
+                grads.append(g)
+            else:
+                grads.append(None)
+        return grads[0], grads[1], grads[2], None, None, None, None
+
+
+def loss_mean(pred, sign):
+    return MeanLossFn.apply(pred, float(sign))
+
+
+def loss_bce(pred, target):
+    """`target` may be a python number (constant target) or a tensor."""
+    if isinstance(target, torch.Tensor):
+        return PointLossFn.apply(pred, target, 0.0, "bce")
+    return PointLossFn.apply(pred, None, float(target), "bce")
+
+
+def loss_mse(pred, target):
+    if isinstance(target, torch.Tensor):
+        return PointLossFn.apply(pred, target, 0.0, "mse")
+    return PointLossFn.apply(pred, None, float(target), "mse")
+
+
+def loss_l1(a, b):
+    return L1LossFn.apply(a, b)
+
+
+def combine(a, c0, b=None, c1=0.0, c=None, c2=0.0, want_ratio=False):
+    return CombineFn.apply(a, b, c, float(c0), float(c1), float(c2), want_ratio)
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# WGAN-GP
+# ----------------------------------------------------------------------------------------------------------------
+def gp_interpolate(alpha, real, fake):
+    """alpha[b]*real[b] + (1-alpha[b])*fake[b]; returns a fresh leaf that requires grad (no gradient flows to
+    real/fake: the reference detaches fake and real is data, WassersteinGANGP.py:69,89)."""
+    real = _dense_like(real.detach())
+    fake = _match_layout(_dense_like(fake.detach()), real)
+    if real.shape != fake.shape:
+        raise _hip.HipError("interpolation operands differ in shape: %s vs %s" % (tuple(real.shape), tuple(fake.shape)))
+    b = real.shape[0]
+    alpha = alpha.reshape(-1)
+    if alpha.numel() != b or not alpha.is_contiguous():
+        raise _hip.HipError("alpha must hold one value per sample")
+    _require_gpu(alpha)
+    out = torch.empty_like(real)
+    call("vg_gp_interp", _ptr(alpha), _ptr(real), _ptr(fake), _ptr(out), b, c_size_t(real.numel() // b), _stream())
+    return out.requires_grad_(True)
+
+
+class GradPenaltyFn(Function):
+    """mean_b (||g_b||_2 - 1)^2 over per-sample gradients g (any layout: the norm runs over all elements of a sample)."""
+
+    @staticmethod
+    def forward(ctx, g):
+        g = _dense_like(g)
+        b = g.shape[0]
+        d = g.numel() // b
+        norms = torch.empty(b, dtype=torch.float32, device=g.device)
+        call("vg_gp_rownorm", _ptr(g), _ptr(norms), b, c_size_t(d), _stream())
+        out = torch.empty((), dtype=torch.float32, device=g.device)
+        call("vg_gp_penalty_fwd", _ptr(norms), b, _ptr(out), _stream())
+        ctx.save_for_backward(g, norms)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gout):
+        g, norms = ctx.saved_tensors
+        b = g.shape[0]
+        dg = torch.empty_like(g)
+        call("vg_gp_penalty_bwd", _ptr(gout), _ptr(g), _ptr(norms), _ptr(dg), b, c_size_t(g.numel() // b), _stream())
+        return dg
+
+
+def gradient_penalty(grads):
+    return GradPenaltyFn.apply(grads)
+
+
+def fill_(t, value):
+    """In-place constant fill (no autograd)."""
+    _require_gpu(t)
+    call("vg_fill", _ptr(t), c_float(value), c_size_t(t.numel()), _stream())
+    return t
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# conditional inputs
+# ----------------------------------------------------------------------------------------------------------------
+class ConcatFn(Function):
+    """Channel concatenation with the vector->image tiling of the reference's utils.concatenate (utils.py:52-90)."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        _require_gpu(a)
+        _require_gpu(b)
+        if a.shape[0] != b.shape[0]:
+            raise AssertionError("Tensors to concatenate must have same dim 0. Tensor1: {}. Tensor2: {}.".format(
+                a.shape[0], b.shape[0]))
+        n = a.shape[0]
+        if a.dim() == 2 and b.dim() == 2:
+            a_, b_ = a.contiguous(), b.contiguous()
+            out = torch.empty((n, a.shape[1] + b.shape[1]), dtype=torch.float32, device=a.device)
+            call("vg_concat_channels", _ptr(a_), a.shape[1], 0, _ptr(b_), b.shape[1], 0, _ptr(out), n, 1, _stream())
+            ctx.meta = (a.shape[1], b.shape[1], 0, 0, tuple(a.shape), tuple(b.shape))
+            return out
+        if a.dim() == 4 and b.dim() == 4:
+            if a.shape[2:] != b.shape[2:]:
+                raise _hip.HipError("images to concatenate differ in size: %s vs %s" % (tuple(a.shape), tuple(b.shape)))
+            a_, b_ = to_nhwc(a), to_nhwc(b)
+            h, w = a.shape[2:]
+            abc, bbc = 0, 0
+        elif a.dim() == 4 and b.dim() == 2:
+            a_, b_ = to_nhwc(a), b.contiguous()
+            h, w = a.shape[2:]
+            abc, bbc = 0, 1
+        elif a.dim() == 2 and b.dim() == 4:
+            a_, b_ = a.contiguous(), to_nhwc(b)
+            h, w = b.shape[2:]
+            abc, bbc = 1, 0
+        else:
+            raise NotImplementedError("tensor1 and tensor2 must have 2 or 4 dimensions. Given: {} and {}.".format(
+                a.shape, b.shape))
+        c1, c2 = a.shape[1], b.shape[1]
+        out = torch.empty((n, c1 + c2, h, w), dtype=torch.float32, device=a.device, memory_format=CL)
+        call("vg_concat_channels", _ptr(a_), c1, abc, _ptr(b_), c2, bbc, _ptr(out), n, h * w, _stream())
+        ctx.meta = (c1, c2, abc, bbc, tuple(a.shape), tuple(b.shape))
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gout):
+        c1, c2, abc, bbc, ashape, bshape = ctx.meta
+        gout = _dense_like(gout)
+        pixels = gout.numel() // (c1 + c2)
+        grads = []
+        for need, c0, cp, bc, shape in ((ctx.needs_input_grad[0], 0, c1, abc, ashape),
+                                        (ctx.needs_input_grad[1], c1, c2, bbc, bshape)):
+            if not need or bc:
+                # a tiled vector (label / latent code) gets no gradient on the training path
+                grads.append(None)
+                continue
+            if len(shape) == 4:
+                g = torch.empty(shape, dtype=torch.float32, device=gout.device, memory_format=CL)
+            else:
+                g = torch.empty(shape, dtype=torch.float32, device=gout.device)
+            call("vg_slice_channels", _ptr(gout), c1 + c2, c0, cp, _ptr(g), c_size_t(pixels), _stream())
+            grads.append(g)
+        return grads[0], grads[1]
+
+
+def concatenate(a, b):
+    return ConcatFn.apply(a, b)
+
+
+class FlattenFn(Function):
+    """[N,C,H,W] -> [N, C*H*W] in NCHW element order (what nn.Flatten computes)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        ctx.shape = tuple(x.shape)
+        x = to_nchw(x)
+        return x.view(x.shape[0], -1)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.reshape(ctx.shape)
+
+
+def flatten(x):
+    if x.dim() <= 2:
+        return x
+    n, c, h, w = x.shape
+    if c == 1 or h * w == 1:
+        # memory order is the same in both layouts: a pure view
+        return x.reshape(n, c * h * w)
+    return FlattenFn.apply(x)

@@ -1,0 +1,134 @@
+"""Fused optimizer steps on the HIP kernels, driven from the user's own torch.optim object.
+
+The reference calls `self.optimizers[who].step()` (AbstractGenerativeModel.py:374-378) and, for WGAN, clamps the
+critic afterwards (WassersteinGAN.py:74-81).  Here the hyper-parameters and the state tensors stay inside the
+torch optimizer (`optimizer.state_dict()` keeps working and can be loaded into stock torch), but the arithmetic
+runs in one kernel per parameter tensor: gradient pre-scale (data-parallel mean), moment updates, parameter
+update and the optional clamp in a single pass over memory.
+"""
+import math
+from ctypes import byref, c_float, c_size_t
+
+import torch
+
+from .. import _hip
+from .._hip import AdamCfg, RmspropCfg, SgdCfg, _ptr, _stream, call
+
+_NO_CLAMP = (1.0, -1.0)  # lo > hi disables the clamp inside the kernels
+
+
+def _zeros_like(p):
+    t = torch.empty_like(p, memory_format=torch.preserve_format)
+    call("vg_fill", _ptr(t), c_float(0.0), c_size_t(t.numel()), _stream())
+    return t
+
+
+def _as_float(v):
+    return float(v.item()) if isinstance(v, torch.Tensor) else float(v)
+
+
+def _check_flags(group, kind):
+    for flag in ("capturable", "differentiable"):
+        if group.get(flag, False):
+            raise NotImplementedError("%s(%s=True) is not supported by the HIP engine" % (kind, flag))
+
+
+def _grad_mem(p):
+    g = p.grad
+    if g.stride() != p.stride():
+        # elementwise kernels walk raw memory: gradient and parameter must share one memory order
+        if p.dim() == 4:
+            from . import ops
+            g = ops.to_nhwc(g) if p.is_contiguous(memory_format=torch.channels_last) else ops.to_nchw(g)
+        if g.stride() != p.stride():
+            raise _hip.HipError("gradient strides %s differ from parameter strides %s" % (g.stride(), p.stride()))
+    return g
+
+
+def fused_step(optimizer, grad_scale=1.0, clamp=None):
+    """One optimizer step for every parameter that has a gradient. `clamp=(lo, hi)` clamps after the update."""
+    lo, hi = clamp if clamp is not None else _NO_CLAMP
+    kind = type(optimizer)
+    if kind is torch.optim.RMSprop:
+        _rmsprop(optimizer, grad_scale, lo, hi)
+    elif kind in (torch.optim.Adam, torch.optim.AdamW):
+        _adam(optimizer, grad_scale, lo, hi, decoupled=kind is torch.optim.AdamW)
+    elif kind is torch.optim.SGD:
+        _sgd(optimizer, grad_scale, lo, hi)
+    else:
+        raise NotImplementedError(
+            "optimizer %s has no fused MI355X kernel (supported: RMSprop, Adam, AdamW, SGD)" % kind.__name__)
+
+
+def _rmsprop(opt, grad_scale, lo, hi):
+    for group in opt.param_groups:
+        _check_flags(group, "RMSprop")
+        sign = -1.0 if group.get("maximize", False) else 1.0
+        for p in group["params"]:
+            if p.grad is None:
+                continue
+            state = opt.state[p]
+            if len(state) == 0:
+                state["step"] = torch.tensor(0.0)
+                state["square_avg"] = _zeros_like(p)
+                if group["momentum"] > 0:
+                    state["momentum_buffer"] = _zeros_like(p)
+                if group["centered"]:
+                    state["grad_avg"] = _zeros_like(p)
+            state["step"] += 1
+            cfg = RmspropCfg(_as_float(group["lr"]), group["alpha"], group["eps"], group["weight_decay"],
+                             group["momentum"], 1 if group["centered"] else 0, sign * grad_scale, lo, hi)
+            call("vg_rmsprop_step", _ptr(p.data), _ptr(_grad_mem(p)), _ptr(state["square_avg"]),
+                 _ptr(state.get("momentum_buffer")), _ptr(state.get("grad_avg")), c_size_t(p.numel()), byref(cfg),
+                 _stream())
+
+
+def _adam(opt, grad_scale, lo, hi, decoupled):
+    for group in opt.param_groups:
+        _check_flags(group, "Adam")
+        sign = -1.0 if group.get("maximize", False) else 1.0
+        beta1, beta2 = group["betas"]
+        lr = _as_float(group["lr"])
+        for p in group["params"]:
+            if p.grad is None:
+                continue
+            state = opt.state[p]
+            if len(state) == 0:
+                state["step"] = torch.tensor(0.0)
+                state["exp_avg"] = _zeros_like(p)
+                state["exp_avg_sq"] = _zeros_like(p)
+                if group["amsgrad"]:
+                    state["max_exp_avg_sq"] = _zeros_like(p)
+            state["step"] += 1
+            step = float(state["step"])
+            # host-side doubles, exactly as torch's single-tensor Adam forms them
+            bias_correction1 = 1 - beta1 ** step
+            bias_correction2 = 1 - beta2 ** step
+            cfg = AdamCfg(lr, beta1, beta2, group["eps"], group["weight_decay"], lr / bias_correction1,
+                          math.sqrt(bias_correction2), 1 if group["amsgrad"] else 0, 1 if decoupled else 0,
+                          sign * grad_scale, lo, hi)
+            call("vg_adam_step", _ptr(p.data), _ptr(_grad_mem(p)), _ptr(state["exp_avg"]), _ptr(state["exp_avg_sq"]),
+                 _ptr(state.get("max_exp_avg_sq")), c_size_t(p.numel()), byref(cfg), _stream())
+
+
+def _sgd(opt, grad_scale, lo, hi):
+    for group in opt.param_groups:
+        _check_flags(group, "SGD")
+        sign = -1.0 if group.get("maximize", False) else 1.0
+        for p in group["params"]:
+            if p.grad is None:
+                continue
+            state = opt.state[p]
+            first = 0
+            if group["momentum"] != 0 and "momentum_buffer" not in state:
+                state["momentum_buffer"] = _zeros_like(p)
+                first = 1
+            cfg = SgdCfg(_as_float(group["lr"]), group["momentum"], group["dampening"], group["weight_decay"],
+                         1 if group["nesterov"] else 0, first, sign * grad_scale, lo, hi)
+            call("vg_sgd_step", _ptr(p.data), _ptr(_grad_mem(p)), _ptr(state.get("momentum_buffer")),
+                 c_size_t(p.numel()), byref(cfg), _stream())
+
+
+def clamp_(params, lo, hi):
+    for p in params:
+        call("vg_clamp", _ptr(p.data), c_size_t(p.numel()), c_float(lo), c_float(hi), _stream())

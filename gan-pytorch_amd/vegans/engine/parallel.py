@@ -1,0 +1,177 @@
+"""Data-parallel training: one process per GPU, batch sharded by contiguous rows, gradients summed over RCCL.
+
+The reference's multi-GPU path is `torch.nn.DataParallel` inside one process (vegans/utils/networks.py:39-41):
+every forward it re-broadcasts the weights, scatters contiguous row chunks of the batch, and its backward reduces
+gradients to device 0.  Here each rank keeps its own resident replica; per batch it takes the same contiguous
+row chunk DataParallel's scatter would give it (`torch.chunk` sizes), computes losses as means over its rows,
+and after backward the weight gradients of the network being trained are all-reduced (sum) in a few buckets.
+Each bucket's all-reduce is issued from a post-accumulate hook as soon as its last gradient exists, so it
+overlaps with the rest of backward; the 1/world (or rows/global_rows) weight is folded into the fused optimizer
+kernel, which then applies the identical update on every rank.  BatchNorm statistics stay per rank, as they
+are per replica under DataParallel.
+"""
+from ctypes import c_float, c_size_t
+
+import torch
+import torch.distributed as dist
+
+from .._hip import _ptr, _stream, call
+
+BUCKETS_PER_NET = 3
+
+
+def _dist_on():
+    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+
+
+def is_main():
+    return (not (dist.is_available() and dist.is_initialized())) or dist.get_rank() == 0
+
+
+def chunk_bounds(n_rows, world, rank):
+    """Row range [lo, hi) that `torch.chunk(batch, world)` (DataParallel's scatter) gives to `rank`."""
+    size = (n_rows + world - 1) // world
+    lo = min(rank * size, n_rows)
+    hi = min(lo + size, n_rows)
+    return lo, hi
+
+
+class _Single:
+    world, rank = 1, 0
+    global_rows = 0
+
+    def shard(self, rows):
+        return rows
+
+
+class _Sharded:
+    def __init__(self, world, rank):
+        self.world, self.rank = world, rank
+        self.global_rows = 0
+        self.local_rows = 0
+
+    def shard(self, rows):
+        self.global_rows = len(rows)
+        lo, hi = chunk_bounds(len(rows), self.world, self.rank)
+        if hi <= lo:
+            raise RuntimeError("batch of %d rows leaves rank %d of %d without data; use a batch size that is a "
+                               "multiple of the number of GPUs" % (len(rows), self.rank, self.world))
+        self.local_rows = hi - lo
+        return rows[lo:hi]
+
+
+def context(model):
+    """Decide how `model.fit` shards its batches. ngpu > 1 needs an initialised process group (one rank per GPU)."""
+    ngpu = getattr(model, "ngpu", 0) or 0
+    if ngpu > 1:
+        if not _dist_on():
+            raise RuntimeError(
+                "ngpu=%d: multi-GPU training runs one process per GPU. Launch the script with "
+                "`python -m torch.distributed.run --nproc-per-node %d ...` and call "
+                "torch.distributed.init_process_group('nccl') before constructing the model." % (ngpu, ngpu))
+        ctx = _Sharded(dist.get_world_size(), dist.get_rank())
+        model._dp = ctx
+        for name, net in model.neural_nets.items():
+            if not hasattr(net, "_vg_reducer"):
+                net._vg_reducer = GradReducer(list(net.parameters()))
+        return ctx
+    model._dp = _Single()
+    return model._dp
+
+
+def _scaled_copy(src, weight, dst):
+    call("vg_scale", _ptr(src), c_float(weight), _ptr(dst), c_size_t(src.numel()), _stream())
+
+
+class GradReducer:
+    """Bucketed gradient all-reduce for one network. `copy(src, weight, dst)` writes weight*src into the bucket
+    (the HIP scale kernel; host-logic tests pass their own)."""
+
+    def __init__(self, params, n_buckets=BUCKETS_PER_NET, copy=_scaled_copy):
+        self._copy = copy
+        params = [p for p in params if p.requires_grad]
+        # gradients become available roughly in reverse parameter order during backward
+        order = list(reversed(params))
+        total = sum(p.numel() for p in order)
+        cap = max((total + n_buckets - 1) // n_buckets, 1)
+        self.buckets = []
+        cur, cur_n = [], 0
+        for p in order:
+            cur.append(p)
+            cur_n += p.numel()
+            if cur_n >= cap:
+                self.buckets.append(cur)
+                cur, cur_n = [], 0
+        if cur:
+            self.buckets.append(cur)
+        self.flat = [torch.empty(sum(p.numel() for p in b), dtype=torch.float32, device=b[0].device)
+                     for b in self.buckets]
+        self.where = {}
+        for bi, b in enumerate(self.buckets):
+            off = 0
+            for p in b:
+                self.where[p] = (bi, off)
+                off += p.numel()
+        self.pending = [0] * len(self.buckets)
+        self.works = []
+        self.local_weight = 1.0
+        self.armed = False
+        for p in params:
+            p.register_post_accumulate_grad_hook(self._on_grad)
+
+    def arm(self, local_weight):
+        """Start collecting the next backward; `local_weight` scales this rank's gradients before the sum."""
+        self.pending = [len(b) for b in self.buckets]
+        self.works = []
+        self.local_weight = float(local_weight)
+        self.armed = True
+
+    def _on_grad(self, p):
+        if not self.armed or p.grad is None:
+            return
+        bi, off = self.where[p]
+        flat = self.flat[bi]
+        view = flat[off:off + p.numel()]
+        g = p.grad
+        self._copy(g, self.local_weight, view)
+        # the optimizer reads the reduced values straight from the bucket, in the parameter's memory order
+        p.grad = view.as_strided(p.shape, g.stride())
+        self.pending[bi] -= 1
+        if self.pending[bi] == 0:
+            self.works.append(dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True))
+
+    def finish(self):
+        """Flush buckets whose parameters got no gradient this time and wait for every all-reduce."""
+        if not self.armed:
+            return
+        for bi, left in enumerate(self.pending):
+            if 0 < left < len(self.buckets[bi]):
+                self.works.append(dist.all_reduce(self.flat[bi], op=dist.ReduceOp.SUM, async_op=True))
+        for w in self.works:
+            w.wait()
+        self.works = []
+        self.armed = False
+
+
+def arm(model, who):
+    """Called before backward of a sub-step: prepare the reducer of the network being trained."""
+    ctx = getattr(model, "_dp", None)
+    if ctx is None or ctx.world == 1:
+        return
+    names = [who] if who is not None else list(model.neural_nets)
+    for name in names:
+        red = getattr(model.neural_nets[name], "_vg_reducer", None)
+        if red is not None:
+            red.arm(ctx.local_rows / float(ctx.global_rows))
+
+
+def reduce_gradients(model, name):
+    """Wait for the all-reduces of network `name`; returns the factor the optimizer applies to the gradients
+    (1.0: the per-rank weights rows/global_rows were applied before the sum)."""
+    ctx = getattr(model, "_dp", None)
+    if ctx is None or ctx.world == 1:
+        return 1.0
+    red = getattr(model.neural_nets[name], "_vg_reducer", None)
+    if red is not None:
+        red.finish()
+    return 1.0

@@ -1,0 +1,217 @@
+/*
+ * vegans_hip.h — C ABI of libvegans_hip.so: the MI355X (gfx950) kernels behind the
+ * VeGANs adversarial training step.
+ *
+ * The reference (tneuer/GAN-pytorch) has no FFI of its own: every arithmetic call on its
+ * training path is a torch call.  Each entry point below names the reference call site
+ * (file:line under the reference tree) whose arithmetic it replaces.
+ *
+ * Conventions
+ *  - all tensors are float32 device memory; activations are NHWC ([N][H][W][C]),
+ *    conv weights are [Co][kh][kw][Ci] (torch "channels_last" storage of a [Co,Ci,kh,kw]
+ *    parameter; a ConvTranspose2d weight [Cin,Cout,kh,kw] stored channels_last is the
+ *    [Co][kh][kw][Ci] weight of the convolution it is the transpose of);
+ *  - `stream` is a hipStream_t passed as void*; every call only enqueues work on it;
+ *  - the library never allocates, frees or synchronises; scratch memory is passed in by
+ *    the caller and sized by the matching *_workspace_bytes query;
+ *  - return value 0 = success, negative = error, text via vg_last_error() (thread local).
+ */
+#ifndef VEGANS_HIP_H
+#define VEGANS_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VG_OK 0
+#define VG_ERR_INVALID (-1)
+#define VG_ERR_LAUNCH (-2)
+#define VG_ERR_WORKSPACE (-3)
+
+/* activation codes shared by the fused norm/activation kernels */
+#define VG_ACT_NONE 0
+#define VG_ACT_RELU 1
+#define VG_ACT_LRELU 2
+#define VG_ACT_TANH 3
+#define VG_ACT_SIGMOID 4
+
+const char* vg_last_error(void);
+int vg_abi_version(void);
+
+/* Geometry of a 2-d cross-correlation y = conv(x, w): x [N][H][W][Ci], w [Co][kh][kw][Ci],
+ * y [N][Ho][Wo][Co], Ho = (H + 2*ph - kh)/sh + 1 (dilation 1, groups 1). */
+typedef struct vg_conv_geom {
+  int32_t N, H, W, Ci;
+  int32_t Co, kh, kw;
+  int32_t Ho, Wo;
+  int32_t sh, sw, ph, pw;
+} vg_conv_geom;
+
+/* ---- dense contractions (MFMA implicit GEMM, exact f32) -------------------------------
+ * Replace torch.nn.Conv2d / ConvTranspose2d / Linear forward and their autograd formulas as
+ * invoked by `self.generator(z)` / `self.adversariat(x)`
+ * (vegans/models/unconditional/AbstractGenerativeModel.py:615,671; vegans/utils/networks.py:45-47)
+ * and by `loss.backward` / `torch.autograd.grad`
+ * (AbstractGenerativeModel.py:367-372; WassersteinGANGP.py:72-79).
+ *
+ *  vg_conv2d_fwd   y  = conv(x, w) (+ bias[Co], nullable)
+ *  vg_conv2d_dgrad gx = conv_transpose(gy, w): gradient of conv w.r.t. x; also the forward
+ *                  of ConvTranspose2d (x plays gy) (+ bias[Ci], nullable)
+ *  vg_conv2d_wgrad gw = sum over pixels of gy (x) x-window: gradient w.r.t. w; needs a
+ *                  workspace of vg_conv2d_wgrad_workspace_bytes(g) bytes (split-K slabs,
+ *                  reduced in a fixed order: results are run-to-run deterministic)
+ * A Linear layer is the geometry H=W=kh=kw=1.
+ */
+int vg_conv2d_fwd(const vg_conv_geom* g, const float* x, const float* w, const float* bias,
+                  float* y, void* stream);
+int vg_conv2d_dgrad(const vg_conv_geom* g, const float* gy, const float* w, const float* bias,
+                    float* gx, void* stream);
+size_t vg_conv2d_wgrad_workspace_bytes(const vg_conv_geom* g);
+int vg_conv2d_wgrad(const vg_conv_geom* g, const float* gy, const float* x, float* gw,
+                    void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- layout ---------------------------------------------------------------------------
+ * NCHW <-> NHWC copies at the API boundary (user arrays are NCHW: AbstractGenerativeModel.py:319,
+ * :672-674) and the label broadcast-concatenate of vegans/utils/utils.py:52-90. */
+int vg_nchw_to_nhwc(const float* src, float* dst, int N, int C, int HW, void* stream);
+int vg_nhwc_to_nchw(const float* src, float* dst, int N, int C, int HW, void* stream);
+/* out[n][p][0:C1] = a[n][p][0:C1]  (a_bcast=0)  or a[n][0:C1] tiled over the HW pixels (a_bcast=1);
+ * out[n][p][C1:C1+C2] likewise from b.  NHWC; bit-exact copies. */
+int vg_concat_channels(const float* a, int C1, int a_bcast, const float* b, int C2, int b_bcast,
+                       float* out, int N, int HW, void* stream);
+/* dst[p][0:Cp] = src[p][c0:c0+Cp] over `pixels` rows of Ctot channels: the gradient of vg_concat_channels with
+ * respect to a non-broadcast part (labels and latent vectors receive no gradient on this path). */
+int vg_slice_channels(const float* src, int Ctot, int c0, int Cp, float* dst, size_t pixels, void* stream);
+/* out[c] = sum_m x[m][c]  (bias gradients); rows reduced in a fixed order. workspace: vg_colsum_workspace_bytes */
+size_t vg_colsum_workspace_bytes(int M, int C);
+int vg_colsum(const float* x, float* out, int M, int C, void* workspace, size_t workspace_bytes, void* stream);
+/* out[m][c] = v[c]  (backward of vg_colsum) */
+int vg_bcast_rows(const float* v, float* out, int M, int C, void* stream);
+/* out = a + b ; out = a * s (plain elementwise helpers used by gradient accumulation) */
+int vg_add(const float* a, const float* b, float* out, size_t n, void* stream);
+int vg_scale(const float* a, float s, float* out, size_t n, void* stream);
+int vg_fill(float* out, float v, size_t n, void* stream);
+/* out[0] = c0*a[0] + c1*b[0] + c2*c[0] (b, c nullable) and, if ratio_b_over_a is non-null, b[0]/a[0]: the scalar
+ * epilogue `0.5*(fake+real) + lmbda_grad*GP` and `RealFakeRatio` of AbstractGAN1v1.py:85-91 /
+ * WassersteinGANGP.py:100-107 without a host round trip. */
+int vg_scalar_combine(const float* a, float c0, const float* b, float c1, const float* c, float c2, float* out,
+                      float* ratio_b_over_a, void* stream);
+
+/* ---- BatchNorm (training and eval mode) + activations ----------------------------------
+ * Replace torch.nn.BatchNorm1d/2d, LeakyReLU, ReLU, Tanh, Sigmoid inside the user networks
+ * (examples/example_input_formats.py:52-77,141-165; notebooks/02_mnist.ipynb:219-227),
+ * including the first and second derivative formulas autograd applies for WassersteinGANGP.py:72-82.
+ * x is [M][C] (M = N*H*W pixels). */
+size_t vg_bn_workspace_bytes(int M, int C);
+/* batch statistics: mean[c], invstd[c] = 1/sqrt(biased var + eps); if running_mean/var are non-null they
+ * are updated in place: r = (1-momentum)*r + momentum*stat (unbiased variance), as torch does. */
+int vg_bn_stats(const float* x, int M, int C, float eps, float momentum, float* mean, float* invstd,
+                float* running_mean, float* running_var, void* workspace, size_t workspace_bytes,
+                void* stream);
+/* invstd[c] = 1/sqrt(var[c] + eps) (eval mode uses the running statistics) */
+int vg_bn_invstd_from_var(const float* var, float* invstd, int C, float eps, void* stream);
+/* y = act((x - mean) * invstd * gamma + beta); gamma/beta nullable (affine=False) */
+int vg_bn_apply(const float* x, const float* mean, const float* invstd, const float* gamma,
+                const float* beta, float* y, int M, int C, int act, float slope, void* stream);
+/* training-mode backward: sums[0:C] = sum gy, sums[C:2C] = sum gy*xhat (=> gbeta, ggamma), then
+ * gx = gamma*invstd*(gy - mean(gy) - xhat*mean(gy*xhat)) */
+int vg_bn_bwd_reduce(const float* gy, const float* x, const float* mean, const float* invstd, int M, int C,
+                     float* sums, void* workspace, size_t workspace_bytes, void* stream);
+int vg_bn_bwd_apply(const float* gy, const float* x, const float* mean, const float* invstd,
+                    const float* gamma, const float* sums, float* gx, int M, int C, void* stream);
+/* eval-mode backward: gx = gy * gamma * invstd */
+int vg_bn_bwd_eval(const float* gy, const float* invstd, const float* gamma, float* gx, int M, int C,
+                   void* stream);
+/* second derivative of the training-mode backward. Inputs: gy, x, the incoming gradients
+ * u = d/d(gx) [M][C] (nullable), v = d/d(ggamma) [C] (nullable), w = d/d(gbeta) [C] (nullable).
+ * sums5[0:5C] = sum gy, sum gy*xhat, sum u, sum u*xhat, sum u*gy.
+ * Outputs: d_gy [M][C], d_x [M][C], d_gamma [C]. */
+int vg_bn_dbwd_reduce(const float* gy, const float* x, const float* u, const float* mean, const float* invstd,
+                      int M, int C, float* sums5, void* workspace, size_t workspace_bytes, void* stream);
+int vg_bn_dbwd_apply(const float* gy, const float* x, const float* u, const float* v, const float* w,
+                     const float* mean, const float* invstd, const float* gamma, const float* sums5,
+                     float* d_gy, float* d_x, float* d_gamma, int M, int C, void* stream);
+
+int vg_act_fwd(const float* x, float* y, size_t n, int act, float slope, void* stream);
+/* gx = gy * act'(.) ; `ref` is the forward INPUT for RELU/LRELU and the forward OUTPUT for TANH/SIGMOID */
+int vg_act_bwd(const float* gy, const float* ref, float* gx, size_t n, int act, float slope, void* stream);
+/* derivative of vg_act_bwd w.r.t. `ref` for TANH/SIGMOID: d_ref = gg * gy * act''-factor(ref) */
+int vg_act_dbwd_ref(const float* gg, const float* gy, const float* ref, float* d_ref, size_t n, int act,
+                    void* stream);
+
+/* ---- losses -----------------------------------------------------------------------------
+ * Each forward writes one scalar out[0]; each backward writes dpred = gout[0] * dloss/dpred.
+ *  mean : sign * mean(pred)                utils.py:45-49 (wasserstein_loss; sign -1 for target ones, +1 zeros)
+ *  bce  : mean(-(t*max(log p,-100) + (1-t)*max(log(1-p),-100)))   VanillaGAN.py:55-56
+ *  mse  : mean((p - t)^2)                                         LSGAN.py:52-53
+ *  l1   : mean(|a - b|)                     LRGAN.py:73-74,103-105; ConditionalPix2Pix.py:57-58,66-68
+ * workspace: vg_reduce_workspace_bytes(n). */
+size_t vg_reduce_workspace_bytes(size_t n);
+int vg_loss_mean_fwd(const float* pred, size_t n, float sign, float* out, void* ws, size_t ws_bytes, void* stream);
+int vg_loss_mean_bwd(const float* gout, size_t n, float sign, float* dpred, void* stream);
+/* `target` is a tensor of n targets, or null for the constant target `tconst` (ones_like / zeros_like call sites) */
+int vg_loss_bce_fwd(const float* pred, const float* target, float tconst, size_t n, float* out, void* ws, size_t ws_bytes,
+                    void* stream);
+int vg_loss_bce_bwd(const float* gout, const float* pred, const float* target, float tconst, size_t n, float* dpred,
+                    void* stream);
+int vg_loss_mse_fwd(const float* pred, const float* target, float tconst, size_t n, float* out, void* ws, size_t ws_bytes,
+                    void* stream);
+int vg_loss_mse_bwd(const float* gout, const float* pred, const float* target, float tconst, size_t n, float* dpred,
+                    void* stream);
+int vg_loss_l1_fwd(const float* a, const float* b, size_t n, float* out, void* ws, size_t ws_bytes, void* stream);
+/* da and db are each nullable (only one side may need a gradient) */
+int vg_loss_l1_bwd(const float* gout, const float* a, const float* b, size_t n, float* da, float* db, void* stream);
+
+/* ---- WGAN-GP penalty ----------------------------------------------------------------------
+ * WassersteinGANGP.py:67-82 / ConditionalWassersteinGANGP.py:68-83.
+ *  interp  : out[b][i] = alpha[b]*real[b][i] + (1-alpha[b])*fake[b][i]   (B rows of D elements)
+ *  rownorm : norms[b] = sqrt(sum_i g[b][i]^2)
+ *  penalty : out[0] = mean_b (norms[b]-1)^2
+ *  penalty_bwd : dg[b][i] = gout[0] * 2*(norms[b]-1)/(B*norms[b]) * g[b][i]
+ */
+int vg_gp_interp(const float* alpha, const float* real, const float* fake, float* out, int B, size_t D,
+                 void* stream);
+int vg_gp_rownorm(const float* g, float* norms, int B, size_t D, void* stream);
+int vg_gp_penalty_fwd(const float* norms, int B, float* out, void* stream);
+int vg_gp_penalty_bwd(const float* gout, const float* g, const float* norms, float* dg, int B, size_t D,
+                      void* stream);
+
+/* ---- optimizers --------------------------------------------------------------------------
+ * torch.optim.RMSprop / Adam single-tensor arithmetic as configured by
+ * AbstractGenerativeModel.py:91-117 and stepped at :374-378, with the WGAN weight clamp of
+ * WassersteinGAN.py:74-81 fused in (clamp_lo > clamp_hi disables it).  grad_scale multiplies the
+ * gradient first (1/world_size for data parallel sums).  State tensors are updated in place. */
+typedef struct vg_rmsprop_cfg {
+  float lr, alpha, eps, weight_decay, momentum;
+  int32_t centered;
+  float grad_scale, clamp_lo, clamp_hi;
+} vg_rmsprop_cfg;
+int vg_rmsprop_step(float* param, const float* grad, float* square_avg, float* momentum_buf, float* grad_avg,
+                    size_t n, const vg_rmsprop_cfg* cfg, void* stream);
+typedef struct vg_adam_cfg {
+  float lr, beta1, beta2, eps, weight_decay;
+  float step_size;              /* lr / (1 - beta1^step), computed by the host in double like torch does */
+  float bias_correction2_sqrt;  /* sqrt(1 - beta2^step) */
+  int32_t amsgrad;
+  int32_t decoupled_wd;         /* AdamW: p *= 1 - lr*wd before the update */
+  float grad_scale, clamp_lo, clamp_hi;
+} vg_adam_cfg;
+int vg_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, float* max_exp_avg_sq,
+                 size_t n, const vg_adam_cfg* cfg, void* stream);
+typedef struct vg_sgd_cfg {
+  float lr, momentum, dampening, weight_decay;
+  int32_t nesterov;
+  int32_t first_step;           /* momentum buffer is initialised to the gradient on the first step */
+  float grad_scale, clamp_lo, clamp_hi;
+} vg_sgd_cfg;
+int vg_sgd_step(float* param, const float* grad, float* momentum_buf, size_t n, const vg_sgd_cfg* cfg, void* stream);
+/* p = min(max(p, lo), hi), NaN preserved (torch clamp_) */
+int vg_clamp(float* param, size_t n, float lo, float hi, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VEGANS_HIP_H */

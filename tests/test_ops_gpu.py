@@ -1,0 +1,358 @@
+"""Operator-level parity of the HIP kernels (called through the C ABI via the engine's autograd Functions)
+against plain torch fp32 on the CPU.  Tolerances: the kernels are exact-f32 FMA chains in a different
+summation order than torch's CPU kernels, so outputs agree to ~1e-6 relative to the operand scale; the tests
+use rtol 2e-4 / atol scaled by the reduction length."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _close(a, b, tol=2e-4, what=""):
+    a = a.detach().cpu().double()
+    b = b.detach().cpu().double()
+    assert a.shape == b.shape, (what, a.shape, b.shape)
+    scale = max(b.abs().max().item(), 1e-6)
+    err = (a - b).abs().max().item()
+    assert err <= tol * scale, "%s: max err %.3e vs scale %.3e" % (what, err, scale)
+
+
+CONV_CASES = [
+    # N, Ci, H, W, Co, k, s, p
+    (4, 3, 16, 16, 8, 4, 2, 1),      # image stem, Ci=3 (scalar loader)
+    (2, 64, 16, 16, 128, 4, 2, 1),   # fat DCGAN layer
+    (3, 16, 9, 7, 24, 3, 1, 1),      # odd sizes, 3x3 stride 1
+    (2, 32, 8, 8, 1, 4, 1, 0),       # Co=1
+    (5, 512, 4, 4, 1, 4, 1, 0),      # DCGAN critic head (GEMV)
+    (2, 11, 32, 32, 8, 5, 2, 2),     # Ci=11 conditional input, 5x5
+    (2, 8, 12, 12, 20, 3, 2, 0),     # stride 2, no padding, odd phases
+    (130, 4, 4, 4, 36, 1, 1, 0),     # 1x1 conv, M not a tile multiple
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv2d_fwd_bwd(gpu, case):
+    from vegans.engine import ops
+    N, Ci, H, W, Co, k, s, p = case
+    g = torch.Generator().manual_seed(sum(case))
+    x = torch.randn(N, Ci, H, W, generator=g)
+    w = torch.randn(Co, Ci, k, k, generator=g) * 0.1
+    b = torch.randn(Co, generator=g)
+    xr, wr, br = (t.clone().requires_grad_(True) for t in (x, w, b))
+    yr = F.conv2d(xr, wr, br, stride=s, padding=p)
+    gy = torch.randn(yr.shape, generator=g)
+    yr.backward(gy)
+
+    xd = x.to(gpu).requires_grad_(True)
+    wd = w.to(gpu).requires_grad_(True)
+    bd = b.to(gpu).requires_grad_(True)
+    y = ops.conv2d(xd, wd, bd, (s, s), (p, p))
+    _close(y, yr, what="conv fwd")
+    y.backward(gy.to(gpu))
+    _close(xd.grad, xr.grad, what="conv dgrad")
+    _close(wd.grad, wr.grad, what="conv wgrad")
+    _close(bd.grad, br.grad, what="conv bias grad")
+
+
+CONVT_CASES = [
+    # N, Cin, Hi, Wi, Cout, k, s, p
+    (4, 100, 1, 1, 64, 4, 1, 0),    # latent vector -> 4x4 (single GEMM path)
+    (2, 64, 4, 4, 32, 4, 2, 1),     # DCGAN upsample
+    (2, 16, 8, 8, 3, 4, 2, 1),      # image head, Cout=3
+    (3, 8, 5, 7, 12, 3, 1, 1),      # stride 1
+    (2, 20, 4, 4, 10, 5, 3, 1),     # stride 3, k=5: parity classes with different tap counts
+]
+
+
+@pytest.mark.parametrize("case", CONVT_CASES)
+def test_conv_transpose2d_fwd_bwd(gpu, case):
+    from vegans.engine import ops
+    N, Cin, Hi, Wi, Cout, k, s, p = case
+    g = torch.Generator().manual_seed(sum(case))
+    x = torch.randn(N, Cin, Hi, Wi, generator=g)
+    w = torch.randn(Cin, Cout, k, k, generator=g) * 0.1
+    b = torch.randn(Cout, generator=g)
+    xr, wr, br = (t.clone().requires_grad_(True) for t in (x, w, b))
+    yr = F.conv_transpose2d(xr, wr, br, stride=s, padding=p)
+    gy = torch.randn(yr.shape, generator=g)
+    yr.backward(gy)
+
+    xd = x.to(gpu).requires_grad_(True)
+    wd = w.to(gpu).requires_grad_(True)
+    bd = b.to(gpu).requires_grad_(True)
+    y = ops.conv_transpose2d(xd, wd, bd, (s, s), (p, p))
+    _close(y, yr, what="convT fwd")
+    y.backward(gy.to(gpu))
+    _close(xd.grad, xr.grad, what="convT input grad")
+    _close(wd.grad, wr.grad, what="convT weight grad")
+    _close(bd.grad, br.grad, what="convT bias grad")
+
+
+@pytest.mark.parametrize("shape", [(32, 64, 128), (7, 784, 512), (256, 100, 1), (33, 5, 3)])
+def test_linear(gpu, shape):
+    from vegans.engine import ops
+    B, I, O = shape
+    g = torch.Generator().manual_seed(B + I + O)
+    x = torch.randn(B, I, generator=g)
+    w = torch.randn(O, I, generator=g) * 0.1
+    b = torch.randn(O, generator=g)
+    xr, wr, br = (t.clone().requires_grad_(True) for t in (x, w, b))
+    yr = F.linear(xr, wr, br)
+    gy = torch.randn(yr.shape, generator=g)
+    yr.backward(gy)
+    xd, wd, bd = (t.to(gpu).requires_grad_(True) for t in (x, w, b))
+    y = ops.linear(xd, wd, bd)
+    _close(y, yr, what="linear fwd")
+    y.backward(gy.to(gpu))
+    _close(xd.grad, xr.grad, what="linear dgrad")
+    _close(wd.grad, wr.grad, what="linear wgrad")
+    _close(bd.grad, br.grad, what="linear bias grad")
+
+
+@pytest.mark.parametrize("shape", [(8, 16, 6, 6), (4, 3, 5, 5), (64, 32), (16, 130, 4, 4)])
+def test_batch_norm_train_and_running_stats(gpu, shape):
+    from vegans.engine import ops
+    g = torch.Generator().manual_seed(len(shape) + shape[1])
+    C = shape[1]
+    x = torch.randn(shape, generator=g) * 2 + 0.5
+    gamma = torch.rand(C, generator=g) + 0.5
+    beta = torch.randn(C, generator=g)
+    rm, rv = torch.zeros(C), torch.ones(C)
+    xr, gr, br = (t.clone().requires_grad_(True) for t in (x, gamma, beta))
+    yr = F.batch_norm(xr, rm, rv, gr, br, True, 0.1, 1e-5)
+    gy = torch.randn(shape, generator=g)
+    yr.backward(gy)
+    xd, gd, bd = (t.to(gpu).requires_grad_(True) for t in (x, gamma, beta))
+    rmd, rvd = torch.zeros(C, device=gpu), torch.ones(C, device=gpu)
+    y = ops.batch_norm(xd, gd, bd, rmd, rvd, True, 0.1, 1e-5)
+    _close(y, yr, what="bn fwd")
+    _close(rmd, rm, what="running mean")
+    _close(rvd, rv, what="running var")
+    y.backward(gy.to(gpu))
+    _close(xd.grad, xr.grad, what="bn dx")
+    _close(gd.grad, gr.grad, what="bn dgamma")
+    _close(bd.grad, br.grad, what="bn dbeta")
+
+
+def test_batch_norm_eval(gpu):
+    from vegans.engine import ops
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(4, 8, 5, 5, generator=g)
+    gamma, beta = torch.rand(8, generator=g) + 0.5, torch.randn(8, generator=g)
+    rm, rv = torch.randn(8, generator=g), torch.rand(8, generator=g) + 0.5
+    yr = F.batch_norm(x, rm, rv, gamma, beta, False, 0.1, 1e-5)
+    y = ops.batch_norm(x.to(gpu), gamma.to(gpu), beta.to(gpu), rm.to(gpu), rv.to(gpu), False, 0.1, 1e-5)
+    _close(y, yr, what="bn eval")
+
+
+@pytest.mark.parametrize("act", ["relu", "lrelu", "tanh", "sigmoid"])
+def test_activations_first_and_second_order(gpu, act):
+    from vegans import _hip
+    from vegans.engine import ops
+    code = {"relu": _hip.ACT_RELU, "lrelu": _hip.ACT_LRELU, "tanh": _hip.ACT_TANH, "sigmoid": _hip.ACT_SIGMOID}[act]
+    ref = {"relu": torch.relu, "lrelu": lambda t: F.leaky_relu(t, 0.2), "tanh": torch.tanh, "sigmoid": torch.sigmoid}[act]
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(6, 10, 3, 3, generator=g)
+    gy = torch.randn(6, 10, 3, 3, generator=g)
+    xr = x.clone().requires_grad_(True)
+    yr = ref(xr)
+    (gxr,) = torch.autograd.grad(yr, xr, gy, create_graph=True)
+    xd = x.to(gpu).requires_grad_(True)
+    y = ops.activation(xd, code, 0.2)
+    (gxd,) = torch.autograd.grad(y, xd, gy.to(gpu), create_graph=True)
+    _close(y, yr, what="act fwd")
+    _close(gxd, gxr, what="act bwd")
+    if act in ("tanh", "sigmoid"):
+        (gxr ** 2).sum().backward()
+        ops.loss_mse(gxd, 0.0).backward()   # mean(gx^2): same second-order path up to the 1/n factor
+        _close(xd.grad * gxd.numel(), xr.grad, tol=5e-4, what="act second order")
+
+
+def test_losses(gpu):
+    from vegans.engine import ops
+    g = torch.Generator().manual_seed(5)
+    p = torch.rand(37, 1, generator=g) * 0.98 + 0.01
+    for target in (0.0, 1.0):
+        pr = p.clone().requires_grad_(True)
+        lr = F.binary_cross_entropy(pr, torch.full_like(pr, target))
+        lr.backward()
+        pd = p.to(gpu).requires_grad_(True)
+        ld = ops.loss_bce(pd, target)
+        ld.backward()
+        _close(ld, lr, what="bce")
+        _close(pd.grad, pr.grad, what="bce grad")
+        pr = p.clone().requires_grad_(True)
+        lr = F.mse_loss(pr, torch.full_like(pr, target))
+        lr.backward()
+        pd = p.to(gpu).requires_grad_(True)
+        ld = ops.loss_mse(pd, target)
+        ld.backward()
+        _close(ld, lr, what="mse")
+        _close(pd.grad, pr.grad, what="mse grad")
+    # saturated probabilities hit the -100 clamp exactly like torch
+    sat = torch.tensor([[0.0], [1.0], [0.5]])
+    _close(ops.loss_bce(sat.to(gpu), 1.0), F.binary_cross_entropy(sat, torch.ones_like(sat)), what="bce clamp")
+    for sign in (-1.0, 1.0):
+        pr = p.clone().requires_grad_(True)
+        lr = sign * pr.mean()
+        lr.backward()
+        pd = p.to(gpu).requires_grad_(True)
+        ld = ops.loss_mean(pd, sign)
+        ld.backward()
+        _close(ld, lr, what="mean loss")
+        _close(pd.grad, pr.grad, what="mean loss grad")
+    a, b = torch.randn(5, 3, 8, 8, generator=g), torch.randn(5, 3, 8, 8, generator=g)
+    ar = a.clone().requires_grad_(True)
+    lr = F.l1_loss(ar, b)
+    lr.backward()
+    ad = a.to(gpu).requires_grad_(True)
+    ld = ops.loss_l1(ad, b.to(gpu))
+    ld.backward()
+    _close(ld, lr, what="l1")
+    _close(ad.grad, ar.grad, what="l1 grad")
+    big = torch.randn(300000, generator=g)        # multi-block reduction path
+    _close(ops.loss_mean(big.to(gpu), 1.0), big.double().mean().float(), tol=1e-5, what="big mean")
+
+
+def test_concat_and_layout_bit_exact(gpu):
+    from vegans.engine import ops
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(6, 3, 8, 8, generator=g)
+    onehot = F.one_hot(torch.randint(0, 10, (6,), generator=g), 10).float()
+    out = ops.concatenate(x.to(gpu), onehot.to(gpu))
+    ref = torch.cat((x, onehot.reshape(6, 10, 1, 1).tile(1, 1, 8, 8)), dim=1)
+    assert torch.equal(ops.to_nchw(out).cpu(), ref)
+    z = torch.randn(6, 4, generator=g)
+    out = ops.concatenate(z.to(gpu), x.to(gpu))
+    ref = torch.cat((z.reshape(6, 4, 1, 1).tile(1, 1, 8, 8), x), dim=1)
+    assert torch.equal(ops.to_nchw(out).cpu(), ref)
+    out = ops.concatenate(z.to(gpu), onehot.to(gpu))
+    assert torch.equal(out.cpu(), torch.cat((z, onehot), dim=1))
+    y = torch.randn(6, 5, 8, 8, generator=g)
+    out = ops.concatenate(x.to(gpu), y.to(gpu))
+    assert torch.equal(ops.to_nchw(out).cpu(), torch.cat((x, y), dim=1))
+    # gradient of the image part is the channel slice
+    xd = x.to(gpu).requires_grad_(True)
+    out = ops.concatenate(xd, onehot.to(gpu))
+    gout = torch.randn(6, 13, 8, 8, generator=g)
+    out.backward(gout.to(gpu))
+    assert torch.equal(ops.to_nchw(xd.grad).cpu(), gout[:, :3])
+    # layout round trip
+    t = torch.randn(5, 7, 9, 3, generator=g).to(gpu)
+    assert torch.equal(ops.to_nchw(ops.to_nhwc(t)).cpu(), t.cpu())
+    assert torch.equal(ops.to_nhwc(t).cpu(), t.cpu())  # logical values unchanged by a layout change
+
+
+def test_gradient_penalty_with_bn_critic_double_backward(gpu):
+    """Second-order path: conv -> BN -> leaky relu -> conv -> BN -> leaky relu -> conv, penalty on d out / d in."""
+    from vegans import _hip
+    from vegans.engine import ops
+    g = torch.Generator().manual_seed(21)
+    B = 6
+    x = torch.randn(B, 3, 16, 16, generator=g)
+    w1 = torch.randn(8, 3, 4, 4, generator=g) * 0.2
+    w2 = torch.randn(16, 8, 4, 4, generator=g) * 0.1
+    w3 = torch.randn(1, 16, 4, 4, generator=g) * 0.1
+    g1, b1 = torch.rand(8, generator=g) + 0.5, torch.randn(8, generator=g) * 0.1
+    g2, b2 = torch.rand(16, generator=g) + 0.5, torch.randn(16, generator=g) * 0.1
+
+    def ref_critic(inp, p):
+        w1, g1, b1, w2, g2, b2, w3 = p
+        h = F.conv2d(inp, w1, None, 2, 1)
+        h = F.leaky_relu(F.batch_norm(h, None, None, g1, b1, True, 0.1, 1e-5), 0.2)
+        h = F.conv2d(h, w2, None, 2, 1)
+        h = F.leaky_relu(F.batch_norm(h, None, None, g2, b2, True, 0.1, 1e-5), 0.2)
+        return F.conv2d(h, w3, None, 1, 0).flatten(1)
+
+    def hip_critic(inp, p):
+        w1, g1, b1, w2, g2, b2, w3 = p
+        h = ops.conv2d(inp, w1, None, (2, 2), (1, 1))
+        h = ops.activation(ops.batch_norm(h, g1, b1, None, None, True, 0.1, 1e-5), _hip.ACT_LRELU, 0.2)
+        h = ops.conv2d(h, w2, None, (2, 2), (1, 1))
+        h = ops.activation(ops.batch_norm(h, g2, b2, None, None, True, 0.1, 1e-5), _hip.ACT_LRELU, 0.2)
+        return ops.flatten(ops.conv2d(h, w3, None, (1, 1), (0, 0)))
+
+    params = [w1, g1, b1, w2, g2, b2, w3]
+    pr = [t.clone().requires_grad_(True) for t in params]
+    xr = x.clone().requires_grad_(True)
+    out = ref_critic(xr, pr)
+    (gr,) = torch.autograd.grad(out, xr, torch.ones_like(out), create_graph=True)
+    pen_r = ((gr.reshape(B, -1).norm(2, dim=1) - 1) ** 2).mean()
+    pen_r.backward()
+
+    pd = [t.to(gpu).requires_grad_(True) for t in params]
+    xd = x.to(gpu).requires_grad_(True)
+    out = hip_critic(xd, pd)
+    ones = ops.fill_(torch.empty_like(out), 1.0)
+    (gd,) = torch.autograd.grad(out, xd, ones, create_graph=True)
+    pen_d = ops.gradient_penalty(gd)
+    pen_d.backward()
+    _close(gd, gr, what="d critic / d input")
+    _close(pen_d, pen_r, what="penalty")
+    for name, a, b in zip(["w1", "g1", "b1", "w2", "g2", "b2", "w3"], pd, pr):
+        if b.grad is None:
+            assert a.grad is None or float(a.grad.abs().max()) < 1e-6
+            continue
+        _close(a.grad, b.grad, tol=1e-3, what="penalty grad " + name)
+
+
+def test_gp_interpolate(gpu):
+    from vegans.engine import ops
+    g = torch.Generator().manual_seed(2)
+    real, fake = torch.randn(5, 3, 4, 4, generator=g), torch.randn(5, 3, 4, 4, generator=g)
+    alpha = torch.rand(5, 1, 1, 1, generator=g)
+    out = ops.gp_interpolate(alpha.to(gpu), real.to(gpu), fake.to(gpu))
+    assert out.requires_grad
+    _close(out, alpha * real + (1 - alpha) * fake, tol=1e-6, what="interp")
+
+
+def test_optimizers_match_torch(gpu):
+    from vegans.engine import optim as hip_optim
+    g = torch.Generator().manual_seed(4)
+    shapes = [(16, 8, 4, 4), (33,), (7, 5)]
+    cases = [
+        (torch.optim.RMSprop, dict(lr=1e-2)),
+        (torch.optim.RMSprop, dict(lr=5e-3, momentum=0.9, centered=True, weight_decay=1e-3)),
+        (torch.optim.Adam, dict(lr=1e-3)),
+        (torch.optim.Adam, dict(lr=1e-3, betas=(0.5, 0.9), amsgrad=True, weight_decay=1e-2)),
+        (torch.optim.AdamW, dict(lr=1e-3)),
+        (torch.optim.SGD, dict(lr=1e-2, momentum=0.9, nesterov=True)),
+    ]
+    for cls, kw in cases:
+        init = [torch.randn(s, generator=g) for s in shapes]
+        pr = [t.clone().requires_grad_(True) for t in init]
+        pd = [t.clone().to(gpu).requires_grad_(True) for t in init]
+        optr, optd = cls(pr, **kw), cls(pd, **kw)
+        for _ in range(4):
+            grads = [torch.randn(s, generator=g) for s in shapes]
+            for a, b, gg in zip(pr, pd, grads):
+                a.grad = gg.clone()
+                b.grad = gg.clone().to(gpu)
+            optr.step()
+            hip_optim.fused_step(optd)
+        for a, b in zip(pr, pd):
+            _close(b, a, tol=2e-6, what="%s %s" % (cls.__name__, kw))
+        # state stays loadable by stock torch
+        sd = optd.state_dict()
+        assert len(sd["state"]) == len(shapes)
+
+
+def test_clamp_fused_and_bit_exact(gpu):
+    from vegans.engine import optim as hip_optim
+    g = torch.Generator().manual_seed(8)
+    init = torch.randn(1000, generator=g) * 0.02
+    grad = torch.randn(1000, generator=g)
+    pr = init.clone().requires_grad_(True)
+    pd = init.clone().to(gpu).requires_grad_(True)
+    pr.grad, pd.grad = grad.clone(), grad.clone().to(gpu)
+    optr, optd = torch.optim.RMSprop([pr], lr=1e-3), torch.optim.RMSprop([pd], lr=1e-3)
+    optr.step()
+    pr.data.clamp_(-0.01, 0.01)
+    hip_optim.fused_step(optd, clamp=(-0.01, 0.01))
+    out = pd.detach().cpu()
+    assert float(out.abs().max()) == float(np.float32(0.01))
+    clipped = pr.detach().abs() >= np.float32(0.01)
+    assert torch.equal(out[clipped], pr.detach()[clipped])      # clamped entries are bit-identical
+    _close(out, pr, tol=2e-6, what="clamped rmsprop")
