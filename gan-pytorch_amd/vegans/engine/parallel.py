@@ -6,8 +6,8 @@ gradients to device 0.  Here each rank keeps its own resident replica; per batch
 row chunk DataParallel's scatter would give it (`torch.chunk` sizes), computes losses as means over its rows,
 and after backward the weight gradients of the network being trained are all-reduced (sum) in a few buckets.
 Each bucket's all-reduce is issued from a post-accumulate hook as soon as its last gradient exists, so it
-overlaps with the rest of backward; the 1/world (or rows/global_rows) weight is folded into the fused optimizer
-kernel, which then applies the identical update on every rank.  BatchNorm statistics stay per rank, as they
+overlaps with the rest of backward; the rank's weight rows/global_rows is applied while the gradient is copied
+into its bucket, and the fused optimizer kernel then applies the identical update on every rank.  BatchNorm statistics stay per rank, as they
 are per replica under DataParallel.
 """
 from ctypes import c_float, c_size_t
@@ -97,11 +97,11 @@ class GradReducer:
         self.buckets = []
         cur, cur_n = [], 0
         for p in order:
-            cur.append(p)
-            cur_n += p.numel()
-            if cur_n >= cap:
+            if cur and cur_n + p.numel() > cap:
                 self.buckets.append(cur)
                 cur, cur_n = [], 0
+            cur.append(p)
+            cur_n += p.numel()
         if cur:
             self.buckets.append(cur)
         self.flat = [torch.empty(sum(p.numel() for p in b), dtype=torch.float32, device=b[0].device)

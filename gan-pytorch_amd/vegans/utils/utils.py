@@ -107,11 +107,10 @@ def _f32(t):
 
 def get_input_dim(dim1, dim2):
     """Shape (without batch axis) of `concatenate` applied to inputs of shapes dim1 and dim2
-    (vegans/utils/utils.py:92-128, including its treatment of an int dim2 when dim1 is an int)."""
+    (vegans/utils/utils.py:92-128).  Ints are accepted for either argument (the reference only copes with an int
+    dim1: its dim2 check at :116 tests the already converted dim1)."""
     d1 = [dim1] if isinstance(dim1, int) else list(dim1)
-    d2 = [dim2] if isinstance(dim1, int) else (list(dim2) if not isinstance(dim2, int) else dim2)
-    if isinstance(d2, int):
-        raise TypeError("object of type 'int' has no len()")
+    d2 = [dim2] if isinstance(dim2, int) else list(dim2)
     if len(d1) == 1 and len(d2) == 1:
         return [d1[0] + d2[0]]
     if len(d1) == 3 and len(d2) == 1:

@@ -1,0 +1,299 @@
+"""Whole-step parity of the HIP engine behind the VeGANs class API.
+
+1. Against the committed golden fixtures (outputs of the reference itself): same initial weights, the recorded
+   latent batches / alphas / fixed noise injected, then `fit` through the public API; every sub-step's losses, the
+   final parameters, BatchNorm buffers and eval-mode samples must match.
+2. Against the CPU oracle over 100 free-running WGAN-GP iterations, and one iteration at the full DCGAN-64 layer
+   sizes.
+3. Teacher-forced at the full DCGAN-64 width: the weight gradients of a generator and a critic sub-step, element
+   by element, before any optimizer touches them.
+Tolerance (fp32 mode): 1e-4 relative, the bound the task states for losses and parameters after 100 steps;
+quantities that can sit at zero get an absolute floor stated next to each check.  Parameters are compared element
+by element with the outlier budget explained in golden_util.compare_network (adaptive optimizers turn
+rounding-noise gradients into full-size steps, identically in the reference).
+"""
+import copy
+
+import numpy as np
+import pytest
+import torch
+
+import golden_util as gu
+
+pytestmark = pytest.mark.gpu
+
+REL = 1e-4
+DRIFT = 2e-2   # bound on every element, noise-driven ones included (see golden_util.compare_network)
+
+
+def _build_model(case, nets, device="cuda"):
+    import vegans.GAN as gan
+    G, D, E = nets
+    kw = dict(generator=G, adversariat=D, x_dim=case["x_dim"], z_dim=case["z_dim"],
+              optim_kwargs=copy.deepcopy(case.get("optim_kwargs")), fixed_noise_size=case.get("fixed_noise_size", 4),
+              device=device, folder=None)
+    if "y_dim" in case:
+        kw["y_dim"] = tuple(case["y_dim"]) if not isinstance(case["y_dim"], int) else case["y_dim"]
+    if case["algo"] == "lrgan":
+        kw["encoder"] = E
+    return getattr(gan, case["cls"])(**kw)
+
+
+def _inject(model, latents, alphas, record):
+    """Feed recorded latent batches and alphas through the model's own draw hooks; log each sub-step's losses."""
+    zs, al = iter(latents), iter(alphas)
+    model.sample = lambda n: next(zs).to("cuda").requires_grad_(True)
+    if hasattr(model, "_draw_alpha"):
+        model._draw_alpha = lambda n: torch.from_numpy(np.asarray(next(al), dtype=np.float32)).to("cuda")
+    orig_backward = model._backward
+
+    def backward(who=None):
+        record.append((who, {k: v.detach() for k, v in model._losses.items()}))
+        return orig_backward(who=who)
+
+    model._backward = backward
+
+
+def _close(got, want, rel, floor, what):
+    got = np.asarray(got, dtype=np.float64)
+    want = np.asarray(want, dtype=np.float64)
+    scale = max(float(np.abs(want).max()), floor)
+    err = float(np.abs(got - want).max())
+    assert err <= rel * scale, "%s: |diff| %.3e > %.1e * %.3e" % (what, err, rel, scale)
+
+
+def _fit(model, case, X, y):
+    kw = dict(epochs=1, batch_size=case["batch"], steps=copy.deepcopy(case.get("steps")), print_every=None,
+              save_losses_every=None, enable_tensorboard=False)
+    if y is None:
+        model.fit(X, **kw)
+    else:
+        model.fit(X, y, **kw)
+
+
+@pytest.mark.parametrize("name", gu.names())
+def test_fit_matches_reference_fixture(gpu, name):
+    fx = gu.load(name)
+    case = fx["meta"]
+    nets = gu.build_nets(case)
+    for net, key in zip(nets, ("Generator", "Adversariat", "Encoder")):
+        if net is not None and key in fx["init"]:   # same starting point as the reference run
+            for k, v in net.state_dict().items():
+                np.testing.assert_array_equal(v.numpy(), fx["init"][key][k])
+    torch.manual_seed(case["seed"])
+    np.random.seed(case["seed"])
+    model = _build_model(case, nets)
+    model.fixed_noise = torch.from_numpy(fx["fixed_noise"]).to("cuda")
+    record = []
+    _inject(model, [torch.from_numpy(z) for z in fx["Z"]], fx["alpha"], record)
+    _fit(model, case, fx["X"], fx["y"])
+
+    rows = gu.loss_rows(fx)
+    assert [w for w, _ in record] == [w for w, _ in rows]
+    for i, ((who, got), (_, want)) in enumerate(zip(record, rows)):
+        assert set(got) == set(want), (i, who)
+        for k, v in want.items():
+            g = float(got[k])
+            if k == "RealFakeRatio":
+                # a quotient of two losses, logged only: 10x looser, and only where the denominator is not tiny
+                if np.isfinite(v) and abs(v) < 1e3:
+                    _close(g, v, 10 * REL, 1e-2, "step %d %s %s" % (i, who, k))
+                continue
+            _close(g, v, REL, 1e-1, "step %d %s %s" % (i, who, k))   # floor: losses are O(0.1..1)
+    names = ["Generator", "Adversariat"] + (["Encoder"] if case["algo"] == "lrgan" else [])
+    problems = []
+    for net in names:
+        network = model.neural_nets[net].network
+        problems += gu.compare_network(network.state_dict(), fx["final"][net], network, REL, DRIFT, net)
+    assert not problems, "\n".join(problems)
+    if fx["y"] is None:
+        samples = model.generate(z=model.fixed_noise)
+    else:
+        samples = model.generate(y=model.fixed_labels, z=model.fixed_noise)
+    assert isinstance(samples, np.ndarray) and samples.shape == fx["samples"].shape
+    # Eval-mode outputs read BatchNorm running means.  Where a biased layer feeds a BatchNorm, (bias - running_mean)
+    # carries the history of that bias's noise-driven random walk (golden_util.shadowed_keys), so the samples of
+    # such generators are only reproducible to the size of that walk; bias-free stacks (DCGAN) must meet REL.
+    noisy = len(gu.shadowed_keys(model.generator.network)) > 0
+    _close(samples, fx["samples"], 20 * REL if noisy else REL, 1e-1, "eval-mode samples")
+    if case["algo"] == "wgan":
+        biggest = max(float(p.detach().abs().max()) for p in model.adversariat.parameters())
+        assert biggest == float(np.float32(case.get("clip_val", 0.01)))      # bit-exact clamp bound
+
+
+def _oracle_and_model(algo, cls, nets_fn, x_dim, z_dim, optim_kwargs, seed=3):
+    from oracle.restated import OracleGAN
+    case = dict(algo=algo, cls=cls, x_dim=x_dim, z_dim=z_dim, optim_kwargs=optim_kwargs, fixed_noise_size=4)
+    torch.manual_seed(seed)
+    np.random.seed(seed)
+    Go, Do = nets_fn()
+    oracle = OracleGAN(algo, Go, Do, x_dim, z_dim, optim_kwargs=copy.deepcopy(optim_kwargs), fixed_noise_size=4)
+    torch.manual_seed(seed)
+    Gm, Dm = nets_fn()
+    model = _build_model(case, (Gm, Dm, None))
+    return oracle, model
+
+
+def _compare_with_oracle(oracle, model):
+    problems = []
+    for name, net_o in oracle.nets.items():
+        want = {k: v.detach().numpy() for k, v in net_o.state_dict().items()}
+        network = model.neural_nets[name].network
+        problems += gu.compare_network(network.state_dict(), want, network, REL, DRIFT, name)
+    assert not problems, "\n".join(problems)
+
+
+def test_wgangp_100_steps_free_running_vs_oracle(gpu):
+    """100 iterations, each side running on its own evolving weights; only Z and alpha are shared."""
+    import bench_configs as cfg
+
+    def nets():
+        return (cfg.seeded_init(cfg.dcgan_generator(nz=16, ngf=8, nc=3, size=16), 1, 0.08),
+                cfg.seeded_init(cfg.dcgan_critic(ndf=8, nc=3, size=16), 2, 0.08))
+
+    okw = {"Generator": {"lr": 2e-4}, "Adversariat": {"lr": 1e-4}}
+    oracle, model = _oracle_and_model("wgangp", "WassersteinGANGP", nets, (3, 16, 16), (16, 1, 1), okw)
+    B, iters = 8, 100
+    X = cfg.synthetic_images(B * iters, (3, 16, 16), seed=5)
+    g = torch.Generator().manual_seed(9)
+    Z = [torch.randn(B, 16, 1, 1, generator=g) for _ in range(iters)]
+    A = [np.random.default_rng(100 + i).random((B, 1, 1, 1)) for i in range(iters)]
+    hist = oracle.fit(X, None, epochs=1, batch_size=B, latents=[z.clone() for z in Z], alphas=A)
+    record = []
+    _inject(model, Z, A, record)
+    model.fit(X, epochs=1, batch_size=B, print_every=None, save_losses_every=None, enable_tensorboard=False)
+    assert len(record) == len(hist) == 2 * iters
+    for key in ("Generator", "Adversariat", "Adversariat_grad"):
+        want = np.array([l[key] for _, l in hist if key in l])
+        got = np.array([float(l[key]) for _, l in record if key in l])
+        _close(got, want, REL, 1e-1, "loss curve " + key)
+    _compare_with_oracle(oracle, model)
+
+
+def test_wgangp_full_width_dcgan64_one_iteration_vs_oracle(gpu):
+    """The north-star layer shapes (ngf = ndf = 64, 3x64x64, z 100) at a batch the CPU oracle finishes in seconds."""
+    import bench_configs as cfg
+
+    def nets():
+        return (cfg.dcgan_init(cfg.dcgan_generator(100, 64, 3, 64), 1), cfg.dcgan_init(cfg.dcgan_critic(64, 3, 64), 2))
+
+    okw = {"Generator": {"lr": 1e-4}, "Adversariat": {"lr": 5e-5}}
+    oracle, model = _oracle_and_model("wgangp", "WassersteinGANGP", nets, (3, 64, 64), (100, 1, 1), okw)
+    B = 16
+    X = cfg.synthetic_images(B, (3, 64, 64), seed=6)
+    g = torch.Generator().manual_seed(10)
+    Z = [torch.randn(B, 100, 1, 1, generator=g)]
+    A = [np.random.default_rng(7).random((B, 1, 1, 1))]
+    hist = oracle.fit(X, None, epochs=1, batch_size=B, latents=[Z[0].clone()], alphas=A)
+    record = []
+    _inject(model, Z, A, record)
+    model.fit(X, epochs=1, batch_size=B, print_every=None, save_losses_every=None, enable_tensorboard=False)
+    for (who, want), (_, got) in zip(hist, record):
+        for k, v in want.items():
+            if k != "RealFakeRatio":
+                _close(float(got[k]), v, REL, 1e-1, "%s %s" % (who, k))
+    _compare_with_oracle(oracle, model)
+
+
+def test_teacher_forced_gradients_full_width_dcgan64(gpu):
+    """Same weights on both sides, one generator and one critic sub-step at ngf = ndf = 64: every weight-gradient
+    element must agree to 1e-4 of the tensor's largest gradient (measured: ~2e-6) before the optimizer runs."""
+    import bench_configs as cfg
+
+    def nets():
+        return (cfg.dcgan_init(cfg.dcgan_generator(100, 64, 3, 64), 1), cfg.dcgan_init(cfg.dcgan_critic(64, 3, 64), 2))
+
+    okw = {"Generator": {"lr": 1e-4}, "Adversariat": {"lr": 5e-5}}
+    oracle, model = _oracle_and_model("wgangp", "WassersteinGANGP", nets, (3, 64, 64), (100, 1, 1), okw)
+    B = 16
+    X = cfg.synthetic_images(B, (3, 64, 64), seed=6)
+    Z = torch.randn(B, 100, 1, 1, generator=torch.Generator().manual_seed(10))
+    A = np.random.default_rng(7).random((B, 1, 1, 1))
+    oracle._set_mode(True)
+    model.train()
+    model._draw_alpha = lambda n: torch.from_numpy(A.astype(np.float32)).to("cuda")
+    Xm, Zm = model._to_device(X), Z.to("cuda")
+    for who in ("Generator", "Adversariat"):
+        losses_o = oracle.losses(who, torch.from_numpy(X), Z.clone(), None, A)
+        oracle.optimizers[who].zero_grad()
+        losses_o[who].backward()
+        model._losses = {}
+        with model._training_only(who):
+            model.calculate_losses(X_batch=Xm, Z_batch=Zm, who=who)
+            model._zero_grad(who=who)
+            model._backward(who=who)
+        _close(float(model._losses[who].detach()), float(losses_o[who]), REL, 1e-1, who + " loss")
+        for (k, po), (_, pm) in zip(oracle.nets[who].named_parameters(), model.neural_nets[who].network.named_parameters()):
+            _close(pm.grad.detach().cpu().numpy(), po.grad.numpy(), REL, 1e-12, "%s grad %s" % (who, k))
+
+
+def test_full_batch_properties_dcgan64(gpu):
+    """At the benchmark's full size (batch 256) the CPU oracle is too slow for the suite, so check properties
+    that do not depend on size: per-sample independence of the BN-free critic (a batch row's output equals the
+    output of that row alone), homogeneity of the bias-free conv stack, and that the penalty of a critic with
+    unit input-gradient norm is zero."""
+    import bench_configs as cfg
+    from vegans.engine import modules, ops
+    D = cfg.dcgan_init(cfg.dcgan_critic(64, 3, 64, batch_norm=False), 2).to("cuda")
+    modules.bind(D)
+    modules.prepare_parameters(D)
+    X = torch.from_numpy(cfg.synthetic_images(256, (3, 64, 64), seed=1)).to("cuda")
+    with torch.no_grad():
+        full = D(X)
+        part = D(X[100:108].contiguous())
+    _close(part.cpu().numpy(), full[100:108].cpu().numpy(), 1e-5, 1e-3, "row independence")
+    x = X.clone().requires_grad_(True)
+    out = D(x)
+    ones = ops.fill_(torch.empty_like(out), 1.0)
+    (g,) = torch.autograd.grad(out, x, ones, create_graph=True)
+    norms = ops.to_nchw(g.detach()).reshape(256, -1).norm(2, dim=1)
+    pen = ops.gradient_penalty(g)
+    want = float(((norms.double() - 1) ** 2).mean())
+    _close(float(pen), want, 1e-5, 1e-3, "penalty value at batch 256")
+    pen.backward()
+    grads = [p.grad for p in D.parameters()]
+    assert all(gr is not None and torch.isfinite(gr).all() for gr in grads)
+
+
+def test_unsupported_layer_and_device_fail_loudly(gpu):
+    import vegans.GAN as gan
+    from torch import nn
+    G = nn.Sequential(nn.Linear(4, 8), nn.Tanh())
+    D_bad = nn.Sequential(nn.Linear(8, 4), nn.GELU(), nn.Linear(4, 1), nn.Sigmoid())
+    with pytest.raises(NotImplementedError):
+        gan.VanillaGAN(G, D_bad, x_dim=8, z_dim=4, folder=None)
+    D = nn.Sequential(nn.Linear(8, 4), nn.LeakyReLU(0.2), nn.Linear(4, 1), nn.Sigmoid())
+    with pytest.raises(ValueError):
+        gan.VanillaGAN(G, D, x_dim=8, z_dim=4, folder=None, device="tpu")
+    with pytest.raises(RuntimeError):
+        gan.VanillaGAN(G, D, x_dim=8, z_dim=4, folder=None, device="cpu")
+    with pytest.raises(TypeError):      # first layer width does not match z_dim
+        gan.VanillaGAN(G, D, x_dim=8, z_dim=5, folder=None)
+    with pytest.raises(AssertionError):  # critic must not end in Sigmoid
+        gan.WassersteinGAN(G, D, x_dim=8, z_dim=4, folder=None)
+    m = gan.VanillaGAN(G, D, x_dim=8, z_dim=4, folder=None)
+    with pytest.raises(KeyError):
+        m.fit(np.zeros((8, 8), dtype=np.float32), steps={"Critic": 2}, enable_tensorboard=False)
+
+
+def test_logging_and_results_api(gpu):
+    import bench_configs as cfg
+    import vegans.GAN as gan
+    G = cfg.seeded_init(cfg.dcgan_generator(nz=16, ngf=8, nc=3, size=16), 1, 0.08)
+    D = cfg.seeded_init(cfg.dcgan_critic(ndf=8, nc=3, size=16), 2, 0.08)
+    m = gan.WassersteinGANGP(G, D, x_dim=(3, 16, 16), z_dim=(16, 1, 1), folder=None, fixed_noise_size=6)
+    X = cfg.synthetic_images(40, (3, 16, 16), seed=2)
+    m.fit(X, epochs=2, batch_size=8, print_every="1e", save_losses_every=2, enable_tensorboard=False)
+    samples, losses = m.get_training_results()
+    assert samples.shape == (6, 3, 16, 16) and samples.dtype == np.float32
+    assert set(losses) == {"Train", "Test"}
+    assert set(losses["Train"]) == {"Generator", "Adversariat", "Adversariat_fake", "Adversariat_real",
+                                    "Adversariat_grad", "RealFakeRatio"}
+    assert len(losses["Train"]["Generator"]) == 5          # 10 steps, logged every 2nd
+    _, by_epoch = m.get_training_results(by_epoch=True)
+    assert len(by_epoch["Train"]["Generator"]) == 2
+    assert not m.generator.training                          # fit leaves the model in eval mode
+    out = m.generate(n=3)
+    assert isinstance(out, np.ndarray) and out.shape == (3, 3, 16, 16)
+    pred = m.predict(X[:5])
+    assert tuple(pred.shape) == (5, 1)
