@@ -1,0 +1,170 @@
+"""Benchmark of the VeGANs adversarial training step on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[1]): WassersteinGANGP, DCGAN-64 generator / BatchNorm critic (ngf = ndf = 64),
+synthetic 3x64x64 images, z_dim = [100,1,1], batch 256 per GPU, fp32, steps G:1 / D:1, RMSprop.  One "step" is one
+pass of the hot loop body over one batch that already sits in HBM (G sub-step + D sub-step with gradient penalty).
+With N > 1 (launched by torch.distributed.run, one rank per GPU) the global batch is 256*N (weak scaling), sharded
+by rows, with bucketed RCCL all-reduce of the gradients.
+
+Prints ONE JSON line on rank 0: metric/value (whole-job images/s), plus
+  roofline     — achieved TFLOP/s of the dominant convolution kernel: algorithmic conv FLOPs of its launches divided
+                 by their HIP-event-timed durations inside the timed region, against the fp32 MFMA peak;
+  cpu_baseline — the CPU oracle (oracle/restated.py, stock torch CPU kernels) timed on the host cores on a bounded
+                 sample of the same workload (rank 0, N = 1 only).
+"""
+import argparse
+import contextlib
+import io
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "gan-pytorch_amd"))
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+import bench_configs as cfg  # noqa: E402
+
+BATCH_PER_GPU = 256
+FP32_MFMA_PEAK_TFLOPS = 157.3      # MI355X dense fp32 matrix peak (v_mfma_f32_32x32x2_f32)
+OPTIM_KWARGS = {"Generator": {"lr": 1e-4}, "Adversariat": {"lr": 5e-5}}
+
+
+def build_model(ngpu):
+    import vegans.GAN as gan
+    G = cfg.dcgan_init(cfg.dcgan_generator(100, 64, 3, 64), 1)
+    D = cfg.dcgan_init(cfg.dcgan_critic(64, 3, 64, batch_norm=True), 2)
+    with contextlib.redirect_stdout(io.StringIO()):
+        model = gan.WassersteinGANGP(G, D, x_dim=(3, 64, 64), z_dim=(100, 1, 1), optim_kwargs=OPTIM_KWARGS,
+                                     fixed_noise_size=16, device="cuda", folder=None, ngpu=ngpu)
+    return model
+
+
+def cpu_baseline(iterations=2, warmup=1):
+    """The oracle on the host cores: same networks, batch 256, fp32, steps 1:1."""
+    from oracle.restated import OracleGAN
+    torch.manual_seed(0)
+    np.random.seed(0)
+    G = cfg.dcgan_init(cfg.dcgan_generator(100, 64, 3, 64), 1)
+    D = cfg.dcgan_init(cfg.dcgan_critic(64, 3, 64, batch_norm=True), 2)
+    oracle = OracleGAN("wgangp", G, D, (3, 64, 64), (100, 1, 1), optim_kwargs=OPTIM_KWARGS, fixed_noise_size=16)
+    X = cfg.synthetic_images(BATCH_PER_GPU * (iterations + warmup), (3, 64, 64), seed=0)
+    oracle.fit(X[:BATCH_PER_GPU * warmup], None, epochs=1, batch_size=BATCH_PER_GPU)
+    t0 = time.perf_counter()
+    oracle.fit(X[BATCH_PER_GPU * warmup:], None, epochs=1, batch_size=BATCH_PER_GPU)
+    dt = time.perf_counter() - t0
+    return {"value": round(BATCH_PER_GPU * iterations / dt, 2), "unit": "images/s", "cores": torch.get_num_threads(),
+            "kind": "port",
+            "sample": "%d WGAN-GP iterations of batch %d (DCGAN-64, fp32) after %d warm-up, oracle/restated.py on torch "
+                      "CPU kernels" % (iterations, BATCH_PER_GPU, warmup)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timing", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit("--gpus %d needs `python -m torch.distributed.run --nproc-per-node %d bench.py ...`" %
+                         (args.gpus, args.gpus))
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    from vegans.engine import ops, parallel
+
+    torch.manual_seed(0)
+    np.random.seed(0)
+    model = build_model(ngpu=world if world > 1 else None)
+    model._create_steps(None)
+    model.train()
+    dp = parallel.context(model)
+    global_batch = BATCH_PER_GPU * world
+    if world > 1:
+        dp.global_rows, dp.local_rows = global_batch, BATCH_PER_GPU
+
+    # synthetic data, resident in HBM before the clock starts: a few distinct batches cycled through
+    pool = [model._to_device(cfg.synthetic_images(BATCH_PER_GPU, (3, 64, 64), seed=100 + 7 * rank + i)) for i in range(4)]
+    zgen = torch.Generator(device="cuda").manual_seed(1234 + rank)
+    latents = [torch.randn(BATCH_PER_GPU, 100, 1, 1, device="cuda", generator=zgen) for _ in range(4)]
+
+    def step(i):
+        model.train_on_batch(pool[i % 4], latents[i % 4])
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    timer = None
+    if not args.no_kernel_timing:
+        timer = ops.ConvTimer()
+        ops.conv_timer = timer
+    fence()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i)
+    fence()
+    elapsed = time.perf_counter() - t0
+    ops.conv_timer = None
+    if world > 1:
+        t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        g_macs, d_macs = cfg.dcgan_forward_macs(64)
+        flops_per_image = 2.0 * (4 * g_macs + 14 * d_macs)     # necessary conv work of one WGAN-GP iteration
+        value = global_batch * args.steps / elapsed
+        out = {
+            "metric": "training images/sec (G+D step) DCGAN-64 WGAN-GP",
+            "value": round(value, 2), "unit": "images/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "WassersteinGANGP DCGAN-64 (ngf=ndf=64, BatchNorm critic), 3x64x64, z=100, "
+                                   "batch 256 per GPU, fp32, steps G1:D1, RMSprop",
+                       "global_batch": global_batch, "parallelism": "dp%d" % world if world > 1 else "single"},
+            "whole_step_conv_tflops": round(value * flops_per_image / 1e12, 2),
+        }
+        if timer is not None:
+            summary = timer.summary()
+            name, (n, ms, fl) = max(summary.items(), key=lambda kv: kv[1][1])
+            achieved = fl / (ms * 1e-3) / 1e12
+            out["roofline"] = {
+                "bound": "mfma", "kernel": name, "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS,
+                "unit": "TFLOP/s", "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                "launches": n, "avg_launch_us": round(1e3 * ms / n, 2),
+                "share_of_step": round(ms / (1e3 * elapsed), 3),
+            }
+            all_ms = sum(v[1] for v in summary.values())
+            all_fl = sum(v[2] for v in summary.values())
+            out["conv_kernels"] = {"time_share_of_step": round(all_ms / (1e3 * elapsed), 3),
+                                   "aggregate_tflops": round(all_fl / (all_ms * 1e-3) / 1e12, 2)}
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -62,3 +62,26 @@ int vg_gemm_kn(const float* A, const float* B, const float* bias, int bias_mod, 
   VG_CHECK_LAUNCH("vg_gemm_kn");
   return VG_OK;
 }
+
+// Name of the kernel variant a contraction dispatches to (mode 0 fwd, 1 dgrad, 2 wgrad), for profilers that want to
+// attribute measured time to a kernel: "igemm<MODE,BM,BN,WAVES_M,B_MC,VA,VB>" as it appears in a kernel trace.
+extern "C" int vg_conv2d_variant(int mode, const vg_conv_geom* g, char* buf, size_t len) {
+  if (int e = vg_check_geom(g, "vg_conv2d_variant")) return e;
+  VG_REQUIRE(buf && len > 0 && mode >= 0 && mode <= 2, "vg_conv2d_variant: bad arguments");
+  int kmode = mode, ncols, va, vb, bmc;
+  if (mode == 0) {
+    ncols = g->Co; va = g->Ci % 4 == 0 ? 4 : 1; vb = (g->kh * g->kw * g->Ci) % 4 == 0 ? 4 : 1; bmc = 0;
+  } else if (mode == 1) {
+    if (g->Ho == 1 && g->Wo == 1 && g->ph == 0 && g->pw == 0 && g->H == g->kh && g->W == g->kw) {
+      kmode = 0; ncols = g->kh * g->kw * g->Ci; va = g->Co % 4 == 0 ? 4 : 1; vb = ncols % 4 == 0 ? 4 : 1;
+    } else {
+      ncols = g->Ci; va = g->Co % 4 == 0 ? 4 : 1; vb = g->Ci % 4 == 0 ? 4 : 1;
+    }
+    bmc = 1;
+  } else {
+    ncols = g->kh * g->kw * g->Ci; va = g->Co % 4 == 0 ? 4 : 1; vb = g->Ci % 4 == 0 ? 4 : 1; bmc = 1;
+  }
+  const int bn = igemm_pick_bn(ncols);
+  snprintf(buf, len, "igemm_kernel<%d, 128, %d, %d, %s, %d, %d>", kmode, bn, bn == 32 ? 4 : 2, bmc ? "true" : "false", va, vb);
+  return VG_OK;
+}

@@ -118,13 +118,52 @@ def _check_shape(t, shape, what):
 # ----------------------------------------------------------------------------------------------------------------
 # raw kernels (no autograd)
 # ----------------------------------------------------------------------------------------------------------------
+class ConvTimer:
+    """Optional event timing of the convolution kernels (installed by the benchmark): start/stop events are
+    recorded on the stream the kernel is launched on; durations are read after the timed region."""
+
+    def __init__(self):
+        self.records = []   # (mode, geometry, start_event, stop_event)
+
+    def launch(self, mode, g, fn):
+        start = torch.cuda.Event(enable_timing=True)
+        stop = torch.cuda.Event(enable_timing=True)
+        start.record()
+        fn()
+        stop.record()
+        self.records.append((mode, g, start, stop))
+
+    def summary(self):
+        """{kernel variant: (launches, total_ms, total_algorithmic_flops)}; call after torch.cuda.synchronize()."""
+        out = {}
+        buf = ctypes.create_string_buffer(128)
+        for mode, g, start, stop in self.records:
+            call("vg_conv2d_variant", mode, ctypes.byref(g.c), buf, c_size_t(128))
+            key = buf.value.decode()
+            flops = 2.0 * g.N * g.Ho * g.Wo * g.Co * g.kh * g.kw * g.Ci
+            n, ms, fl = out.get(key, (0, 0.0, 0.0))
+            out[key] = (n + 1, ms + start.elapsed_time(stop), fl + flops)
+        return out
+
+
+conv_timer = None   # a ConvTimer while a benchmark wants per-kernel durations, else None
+
+
+def _launch_conv(mode, g, fn):
+    if conv_timer is None:
+        fn()
+    else:
+        conv_timer.launch(mode, g, fn)
+
+
 def raw_conv_fwd(g, x, w, bias):
     x, w = to_nhwc(x), _weight_mem(w)
     _check_shape(x, g.x_shape(), "conv input")
     if w.numel() != g.w_numel():
         raise _hip.HipError("weight has %d elements, geometry expects %d" % (w.numel(), g.w_numel()))
     y = _new_act(g.N, g.Co, g.Ho, g.Wo, x, g.flat)
-    call("vg_conv2d_fwd", ctypes.byref(g.c), _ptr(x), _ptr(w), _ptr(bias), _ptr(y), _stream())
+    _launch_conv(0, g, lambda: call("vg_conv2d_fwd", ctypes.byref(g.c), _ptr(x), _ptr(w), _ptr(bias), _ptr(y),
+                                    _stream()))
     return y
 
 
@@ -134,7 +173,8 @@ def raw_conv_dgrad(g, gy, w, bias):
     if w.numel() != g.w_numel():
         raise _hip.HipError("weight has %d elements, geometry expects %d" % (w.numel(), g.w_numel()))
     gx = _new_act(g.N, g.Ci, g.H, g.W, gy, g.flat)
-    call("vg_conv2d_dgrad", ctypes.byref(g.c), _ptr(gy), _ptr(w), _ptr(bias), _ptr(gx), _stream())
+    _launch_conv(1, g, lambda: call("vg_conv2d_dgrad", ctypes.byref(g.c), _ptr(gy), _ptr(w), _ptr(bias), _ptr(gx),
+                                    _stream()))
     return gx
 
 
@@ -150,8 +190,9 @@ def raw_conv_wgrad(g, gy, x, w_shape):
         raise _hip.HipError("weight gradient shape %s does not match the geometry" % (tuple(w_shape),))
     nbytes = _hip.load().vg_conv2d_wgrad_workspace_bytes(ctypes.byref(g.c))
     ws = workspace(nbytes, x.device) if nbytes else None
-    call("vg_conv2d_wgrad", ctypes.byref(g.c), _ptr(gy), _ptr(x), _ptr(gw),
-         ctypes.c_void_p(ws.data_ptr()) if ws is not None else None, c_size_t(nbytes), _stream())
+    _launch_conv(2, g, lambda: call("vg_conv2d_wgrad", ctypes.byref(g.c), _ptr(gy), _ptr(x), _ptr(gw),
+                                    ctypes.c_void_p(ws.data_ptr()) if ws is not None else None, c_size_t(nbytes),
+                                    _stream()))
     return gw
 
 

@@ -244,14 +244,7 @@ class AbstractGenerativeModel(ABC):
                 step = epoch * nr_batches + batch
                 X = self._to_device(dp.shard(X))
                 Z = self._draw_latent(len(X), dp)
-                for name in self.neural_nets:
-                    for _ in range(self.steps[name]):
-                        self._losses = {}
-                        with self._training_only(name):
-                            self.calculate_losses(X_batch=X, Z_batch=Z, who=name)
-                            self._zero_grad(who=name)
-                            self._backward(who=name)
-                        self._step(who=name)
+                self.train_on_batch(X, Z)
 
                 if print_every is not None and step % print_every == 0:
                     self._losses = {}
@@ -274,6 +267,18 @@ class AbstractGenerativeModel(ABC):
 
         self.eval()
         self._clean_up(writers=[writer_train, writer_test])
+
+    def train_on_batch(self, X, Z):
+        """The body of the hot loop (AbstractGenerativeModel.py:321-327) for one batch that already lives on the
+        GPU: every network in `neural_nets` order, `steps[name]` sub-steps each, all on the same X and Z."""
+        for name in self.neural_nets:
+            for _ in range(self.steps[name]):
+                self._losses = {}
+                with self._training_only(name):
+                    self.calculate_losses(X_batch=X, Z_batch=Z, who=name)
+                    self._zero_grad(who=name)
+                    self._backward(who=name)
+                self._step(who=name)
 
     def _draw_latent(self, n_local, dp):
         """One latent batch per data batch (AbstractGenerativeModel.py:320). The training loop never needs
@@ -569,14 +574,7 @@ class AbstractConditionalGenerativeModel(AbstractGenerativeModel):
                 X = self._to_device(dp.shard(X))
                 y = self._to_device(dp.shard(y))
                 Z = self._draw_latent(len(X), dp)
-                for name in self.neural_nets:
-                    for _ in range(self.steps[name]):
-                        self._losses = {}
-                        with self._training_only(name):
-                            self.calculate_losses(X_batch=X, Z_batch=Z, y_batch=y, who=name)
-                            self._zero_grad(who=name)
-                            self._backward(who=name)
-                        self._step(who=name)
+                self.train_on_batch(X, y, Z)
 
                 if print_every is not None and step % print_every == 0:
                     self._losses = {}
@@ -604,6 +602,17 @@ class AbstractConditionalGenerativeModel(AbstractGenerativeModel):
 
         self.eval()
         self._clean_up(writers=[writer_train, writer_test])
+
+    def train_on_batch(self, X, y, Z):
+        """Conditional twin of the hot-loop body (AbstractConditionalGenerativeModel.py:135-141)."""
+        for name in self.neural_nets:
+            for _ in range(self.steps[name]):
+                self._losses = {}
+                with self._training_only(name):
+                    self.calculate_losses(X_batch=X, Z_batch=Z, y_batch=y, who=name)
+                    self._zero_grad(who=name)
+                    self._backward(who=name)
+                self._step(who=name)
 
     def _log_losses(self, X_batch, Z_batch, y_batch, mode):
         self._losses = {}

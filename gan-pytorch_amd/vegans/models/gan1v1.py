@@ -135,7 +135,8 @@ class _PenaltyMixin:
             alpha = dp.shard(np.random.random((dp.global_rows, 1, 1, 1)))
         else:
             alpha = np.random.random((n_local, 1, 1, 1))
-        return torch.from_numpy(alpha.astype(np.float32)).to(self.device)
+        # pinned staging + asynchronous copy: a pageable copy would block the host until the stream drains
+        return torch.from_numpy(alpha.astype(np.float32)).pin_memory().to(self.device, non_blocking=True)
 
     def _gradient_penalty(self, real_images, fake_images):
         alpha = self._draw_alpha(real_images.size(0))

@@ -73,6 +73,11 @@ size_t vg_conv2d_wgrad_workspace_bytes(const vg_conv_geom* g);
 int vg_conv2d_wgrad(const vg_conv_geom* g, const float* gy, const float* x, float* gw,
                     void* workspace, size_t workspace_bytes, void* stream);
 
+/* Name of the kernel template instance the call for (mode, geometry) dispatches to (mode 0 fwd, 1 dgrad, 2 wgrad;
+ * 16-byte aligned tensors assumed), as a kernel trace prints it.  No counterpart in the reference: it exists so a
+ * benchmark can attribute event-timed durations to the kernel the profiler lists. */
+int vg_conv2d_variant(int mode, const vg_conv_geom* g, char* buf, size_t len);
+
 /* ---- layout ---------------------------------------------------------------------------
  * NCHW <-> NHWC copies at the API boundary (user arrays are NCHW: AbstractGenerativeModel.py:319,
  * :672-674) and the label broadcast-concatenate of vegans/utils/utils.py:52-90. */
