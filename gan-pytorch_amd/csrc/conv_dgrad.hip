@@ -4,6 +4,8 @@
 
 int vg_gemm_kn(const float* A, const float* B, const float* bias, int bias_mod, float* out, int M, int Ncols, int K,
                hipStream_t stream);
+int vg_try_dgrad_thin(const vg_conv_geom* g, const float* gy, const float* w, const float* bias, float* gx,
+                      hipStream_t st);
 
 extern "C" int vg_conv2d_dgrad(const vg_conv_geom* g, const float* gy, const float* w, const float* bias,
                                float* gx, void* stream) {
@@ -13,6 +15,8 @@ extern "C" int vg_conv2d_dgrad(const vg_conv_geom* g, const float* gy, const flo
   // 1x1 gradient image covering the whole input window: one GEMM [N][Co] x [Co][kh*kw*Ci].
   if (g->Ho == 1 && g->Wo == 1 && g->ph == 0 && g->pw == 0 && g->H == g->kh && g->W == g->kw)
     return vg_gemm_kn(gy, w, bias, g->Ci, gx, g->N, g->kh * g->kw * g->Ci, g->Co, (hipStream_t)stream);
+
+  if (int r = vg_try_dgrad_thin(g, gy, w, bias, gx, (hipStream_t)stream)) return r < 0 ? r : VG_OK;
 
   IgemmParams p{};
   p.A = gy; p.B = w; p.bias = bias; p.out = gx;
@@ -25,12 +29,13 @@ extern "C" int vg_conv2d_dgrad(const vg_conv_geom* g, const float* gy, const flo
   p.M = g->N * Hc * Wc;
   p.Ktot = 0;  // per class, derived in the kernel
   const int bn = igemm_pick_bn(p.Ncols);
-  p.mtiles = (p.M + 127) / 128;
   p.ntiles = (p.Ncols + bn - 1) / bn;
+  const int bm = igemm_pick_bm(p.M, p.ntiles, g->sh * g->sw, bn);
+  p.mtiles = (p.M + bm - 1) / bm;
   const int va = (g->Co % 4 == 0 && vg_aligned16(gy)) ? 4 : 1;
   const int vb = (g->Ci % 4 == 0 && vg_aligned16(w)) ? 4 : 1;
   dim3 grid((unsigned)(p.mtiles * p.ntiles), 1, (unsigned)(g->sh * g->sw));
-  if (igemm_launch<MODE_DGRAD, true>(p, bn, va, vb, grid, (hipStream_t)stream) != 0)
+  if (igemm_launch<MODE_DGRAD, true>(p, bm, bn, va, vb, grid, (hipStream_t)stream) != 0)
     return vg_fail(VG_ERR_INVALID, "vg_conv2d_dgrad: no kernel variant for bn=%d va=%d vb=%d", bn, va, vb);
   VG_CHECK_LAUNCH("vg_conv2d_dgrad");
   return VG_OK;

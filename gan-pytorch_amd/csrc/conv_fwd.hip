@@ -17,10 +17,14 @@ int vg_check_geom(const vg_conv_geom* g, const char* who) {
   return 0;
 }
 
+int vg_try_fwd_thin(const vg_conv_geom* g, const float* x, const float* w, const float* bias, float* y, hipStream_t st);
+int vg_thin_dgrad_applies(const vg_conv_geom* g);
+
 extern "C" int vg_conv2d_fwd(const vg_conv_geom* g, const float* x, const float* w, const float* bias,
                              float* y, void* stream) {
   if (int e = vg_check_geom(g, "vg_conv2d_fwd")) return e;
   VG_REQUIRE(x && w && y, "vg_conv2d_fwd: null tensor pointer");
+  if (int r = vg_try_fwd_thin(g, x, w, bias, y, (hipStream_t)stream)) return r < 0 ? r : VG_OK;
   IgemmParams p{};
   p.A = x; p.B = w; p.bias = bias; p.out = y;
   p.N = g->N; p.H = g->H; p.W = g->W; p.Ci = g->Ci; p.Co = g->Co; p.KH = g->kh; p.KW = g->kw;
@@ -30,12 +34,13 @@ extern "C" int vg_conv2d_fwd(const vg_conv_geom* g, const float* x, const float*
   p.Ktot = g->kh * g->kw * g->Ci;
   p.bias_mod = g->Co;
   const int bn = igemm_pick_bn(p.Ncols);
-  p.mtiles = (p.M + 127) / 128;
   p.ntiles = (p.Ncols + bn - 1) / bn;
+  const int bm = igemm_pick_bm(p.M, p.ntiles, 1, bn);
+  p.mtiles = (p.M + bm - 1) / bm;
   const int va = (g->Ci % 4 == 0 && vg_aligned16(x)) ? 4 : 1;
   const int vb = (p.Ktot % 4 == 0 && vg_aligned16(w)) ? 4 : 1;
   dim3 grid((unsigned)(p.mtiles * p.ntiles), 1, 1);
-  if (igemm_launch<MODE_FWD, false>(p, bn, va, vb, grid, (hipStream_t)stream) != 0)
+  if (igemm_launch<MODE_FWD, false>(p, bm, bn, va, vb, grid, (hipStream_t)stream) != 0)
     return vg_fail(VG_ERR_INVALID, "vg_conv2d_fwd: no kernel variant for bn=%d va=%d vb=%d", bn, va, vb);
   VG_CHECK_LAUNCH("vg_conv2d_fwd");
   return VG_OK;
@@ -52,12 +57,13 @@ int vg_gemm_kn(const float* A, const float* B, const float* bias, int bias_mod, 
   p.Ho = 1; p.Wo = 1; p.sh = 1; p.sw = 1; p.ph = 0; p.pw = 0;
   p.M = M; p.Ncols = Ncols; p.Ktot = K; p.bias_mod = bias_mod;
   const int bn = igemm_pick_bn(Ncols);
-  p.mtiles = (M + 127) / 128;
   p.ntiles = (Ncols + bn - 1) / bn;
+  const int bm = igemm_pick_bm(M, p.ntiles, 1, bn);
+  p.mtiles = (M + bm - 1) / bm;
   const int va = (K % 4 == 0 && vg_aligned16(A)) ? 4 : 1;
   const int vb = (Ncols % 4 == 0 && vg_aligned16(B)) ? 4 : 1;
   dim3 grid((unsigned)(p.mtiles * p.ntiles), 1, 1);
-  if (igemm_launch<MODE_FWD, true>(p, bn, va, vb, grid, stream) != 0)
+  if (igemm_launch<MODE_FWD, true>(p, bm, bn, va, vb, grid, stream) != 0)
     return vg_fail(VG_ERR_INVALID, "vg_gemm_kn: no kernel variant for bn=%d va=%d vb=%d", bn, va, vb);
   VG_CHECK_LAUNCH("vg_gemm_kn");
   return VG_OK;
@@ -68,20 +74,36 @@ int vg_gemm_kn(const float* A, const float* B, const float* bias, int bias_mod, 
 extern "C" int vg_conv2d_variant(int mode, const vg_conv_geom* g, char* buf, size_t len) {
   if (int e = vg_check_geom(g, "vg_conv2d_variant")) return e;
   VG_REQUIRE(buf && len > 0 && mode >= 0 && mode <= 2, "vg_conv2d_variant: bad arguments");
-  int kmode = mode, ncols, va, vb, bmc;
+  int kmode = mode, ncols, va, vb, bmc, zdim = 1;
+  long long rows = (long long)g->N * g->Ho * g->Wo;
+  if (mode == 0 && g->Co <= 4 && g->Ci % 4 == 0) {
+    snprintf(buf, len, "fwd_thin_kernel<%d, %d>", g->Co, g->kh * g->kw * g->Ci >= 2048 ? 256 : 64);
+    return VG_OK;
+  }
+  const bool gemm_dgrad = g->Ho == 1 && g->Wo == 1 && g->ph == 0 && g->pw == 0 && g->H == g->kh && g->W == g->kw;
+  if (mode == 1 && !gemm_dgrad && vg_thin_dgrad_applies(g)) {
+    snprintf(buf, len, "dgrad_thin_kernel<%d>", g->Ci);
+    return VG_OK;
+  }
   if (mode == 0) {
     ncols = g->Co; va = g->Ci % 4 == 0 ? 4 : 1; vb = (g->kh * g->kw * g->Ci) % 4 == 0 ? 4 : 1; bmc = 0;
   } else if (mode == 1) {
     if (g->Ho == 1 && g->Wo == 1 && g->ph == 0 && g->pw == 0 && g->H == g->kh && g->W == g->kw) {
       kmode = 0; ncols = g->kh * g->kw * g->Ci; va = g->Co % 4 == 0 ? 4 : 1; vb = ncols % 4 == 0 ? 4 : 1;
+      rows = g->N;
     } else {
       ncols = g->Ci; va = g->Co % 4 == 0 ? 4 : 1; vb = g->Ci % 4 == 0 ? 4 : 1;
+      zdim = g->sh * g->sw;
+      rows = (long long)g->N * ((g->H + g->sh - 1) / g->sh) * ((g->W + g->sw - 1) / g->sw);
     }
     bmc = 1;
   } else {
     ncols = g->kh * g->kw * g->Ci; va = g->Co % 4 == 0 ? 4 : 1; vb = g->Ci % 4 == 0 ? 4 : 1; bmc = 1;
+    rows = g->Co;
   }
   const int bn = igemm_pick_bn(ncols);
-  snprintf(buf, len, "igemm_kernel<%d, 128, %d, %d, %s, %d, %d>", kmode, bn, bn == 32 ? 4 : 2, bmc ? "true" : "false", va, vb);
+  const int bm = mode == 2 ? (rows <= 64 && bn != 32 ? 64 : 128) : igemm_pick_bm(rows, (ncols + bn - 1) / bn, zdim, bn);
+  snprintf(buf, len, "igemm_kernel<%d, %d, %d, %d, %s, %d, %d>", kmode, bm, bn, igemm_waves_m(bm, bn),
+           bmc ? "true" : "false", va, vb);
   return VG_OK;
 }

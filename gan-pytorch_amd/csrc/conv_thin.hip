@@ -1,0 +1,207 @@
+// Bandwidth-bound convolution shapes that an MFMA tile cannot use: very few output channels (the critic head
+// Conv(512->1), Linear(->1)) in the forward direction, and very few input channels in the dgrad direction (the
+// generator's ConvTranspose2d(64->3) image head, the critic stem's input gradient).  A 32-wide MFMA column block
+// would be 90 % padding there; these kernels instead stream the activation once with 16-byte accesses and
+// do the few multiply-adds per element on the vector ALU.
+#include "igemm.h"
+
+namespace {
+
+// ---- forward, Co <= 4 ----------------------------------------------------------------------------------------
+// TPP threads cooperate on one output pixel: each walks the (kh,kw,ci) window in float4 steps, then the partial
+// dot products are reduced in a fixed order (wave shuffles, then LDS across waves).
+template <int CO, int TPP>
+__global__ void __launch_bounds__(256) fwd_thin_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                       const float* __restrict__ bias, float* __restrict__ y, int H, int W,
+                                                       int Ci, int KW, int Ho, int Wo, int sh, int sw, int ph, int pw,
+                                                       int M, int K) {
+  constexpr int PPB = 256 / TPP;
+  __shared__ float red[4 * CO];
+  const int t = threadIdx.x % TPP;
+  const int pix = blockIdx.x * PPB + threadIdx.x / TPP;
+  float acc[CO];
+#pragma unroll
+  for (int c = 0; c < CO; ++c) acc[c] = 0.f;
+  if (pix < M) {
+    const int hw = Ho * Wo;
+    const int n = pix / hw, rem = pix - n * hw;
+    const int ho = rem / Wo, wo = rem - ho * Wo;
+    const int bh = ho * sh - ph, bw = wo * sw - pw;
+    const size_t img = (size_t)n * H * W;
+    for (int k4 = 4 * t; k4 < K; k4 += 4 * TPP) {
+      const int tap = k4 / Ci, c = k4 - tap * Ci;
+      const int a = tap / KW, b = tap - a * KW;
+      const int hi = bh + a, wi = bw + b;
+      if ((unsigned)hi < (unsigned)H && (unsigned)wi < (unsigned)W) {
+        const f32x4 xv = *reinterpret_cast<const f32x4*>(x + (img + (size_t)hi * W + wi) * Ci + c);
+#pragma unroll
+        for (int co = 0; co < CO; ++co) {
+          const f32x4 wv = *reinterpret_cast<const f32x4*>(w + (size_t)co * K + k4);
+          acc[co] = fmaf(xv[0], wv[0], fmaf(xv[1], wv[1], fmaf(xv[2], wv[2], fmaf(xv[3], wv[3], acc[co]))));
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int co = 0; co < CO; ++co) acc[co] = vg_wave_sum(acc[co]);
+  if constexpr (TPP == 64) {
+    if ((threadIdx.x & 63) == 0 && pix < M) {
+#pragma unroll
+      for (int co = 0; co < CO; ++co) y[(size_t)pix * CO + co] = acc[co] + (bias ? bias[co] : 0.f);
+    }
+  } else {
+    const int wid = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+      for (int co = 0; co < CO; ++co) red[wid * CO + co] = acc[co];
+    }
+    __syncthreads();
+    if (threadIdx.x == 0 && pix < M) {
+#pragma unroll
+      for (int co = 0; co < CO; ++co)
+        y[(size_t)pix * CO + co] = ((red[co] + red[CO + co]) + (red[2 * CO + co] + red[3 * CO + co])) + (bias ? bias[co] : 0.f);
+    }
+  }
+}
+
+// ---- dgrad, Ci <= 4 ----------------------------------------------------------------------------------------------
+// One block = one parity class (blockIdx.z), one image, an 8 x 32 patch of that class's output pixels.  The gy
+// pixels the patch touches are staged in LDS once per chunk of CC output channels (row stride CC+4 floats:
+// conflict-free ds_read_b128 for consecutive pixels); every thread then owns one output pixel and walks its taps.
+// The weights of a class are block-uniform, so the compiler keeps them in scalar registers.
+constexpr int TI = 8, TJ = 32;
+
+template <int CI>
+__global__ void __launch_bounds__(256) dgrad_thin_kernel(const float* __restrict__ gy, const float* __restrict__ w,
+                                                         const float* __restrict__ bias, float* __restrict__ gx, int H,
+                                                         int W, int Co, int KH, int KW, int Ho, int Wo, int sh, int sw,
+                                                         int ph, int pw, int CC, int itiles, int jtiles) {
+  extern __shared__ __attribute__((aligned(16))) float tile[];
+  const int cls_h = blockIdx.z / sw, cls_w = blockIdx.z - cls_h * sw;
+  const int off_h = ((cls_h - ph) % sh + sh) % sh, off_w = ((cls_w - pw) % sw + sw) % sw;
+  const int Hc = off_h < H ? (H - off_h + sh - 1) / sh : 0;
+  const int Wc = off_w < W ? (W - off_w + sw - 1) / sw : 0;
+  const int nth = cls_h < KH ? (KH - cls_h + sh - 1) / sh : 0;
+  const int ntw = cls_w < KW ? (KW - cls_w + sw - 1) / sw : 0;
+  const int base_h = (off_h + ph - cls_h) / sh, base_w = (off_w + pw - cls_w) / sw;
+  int bid = blockIdx.x;
+  const int jt = bid % jtiles; bid /= jtiles;
+  const int it = bid % itiles;
+  const int n = bid / itiles;
+  const int i0 = it * TI, j0 = jt * TJ;
+  if (i0 >= Hc || j0 >= Wc) return;  // block-uniform
+  const int ti = threadIdx.x / TJ, tj = threadIdx.x % TJ;
+  const int i = i0 + ti, j = j0 + tj;
+  const bool live = i < Hc && j < Wc;
+  float acc[CI];
+#pragma unroll
+  for (int c = 0; c < CI; ++c) acc[c] = 0.f;
+
+  if (nth > 0 && ntw > 0) {
+    const int RH = TI + nth - 1, RW = TJ + ntw - 1;
+    const int ho_lo = i0 + base_h - (nth - 1), wo_lo = j0 + base_w - (ntw - 1);
+    const int LD = CC + 4;
+    const int cq = CC / 4;
+    for (int cc0 = 0; cc0 < Co; cc0 += CC) {
+      __syncthreads();
+      for (int s = threadIdx.x; s < RH * RW * cq; s += 256) {
+        const int p = s / cq, c4 = s - p * cq;
+        const int rh = p / RW, rw = p - rh * RW;
+        const int ho = ho_lo + rh, wo = wo_lo + rw;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if ((unsigned)ho < (unsigned)Ho && (unsigned)wo < (unsigned)Wo && cc0 + 4 * c4 < Co)
+          v = *reinterpret_cast<const f32x4*>(gy + ((size_t)(n * Ho + ho) * Wo + wo) * Co + cc0 + 4 * c4);
+        *reinterpret_cast<f32x4*>(&tile[p * LD + 4 * c4]) = v;
+      }
+      __syncthreads();
+      if (live) {
+        for (int a = 0; a < nth; ++a) {
+          const int kh = cls_h + sh * a;
+          for (int b = 0; b < ntw; ++b) {
+            const int kw = cls_w + sw * b;
+            const float* row = &tile[((ti + nth - 1 - a) * RW + (tj + ntw - 1 - b)) * LD];
+            const float* wt = w + ((size_t)(cc0 * KH + kh) * KW + kw) * CI;   // + co * KH*KW*CI
+            const size_t wstep = (size_t)KH * KW * CI;
+            const int cmax = min(CC, Co - cc0);
+#pragma unroll 4
+            for (int c4 = 0; c4 < cmax; c4 += 4) {
+              const f32x4 g = *reinterpret_cast<const f32x4*>(row + c4);
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                const float* wp = wt + (size_t)(c4 + e) * wstep;
+#pragma unroll
+                for (int ci = 0; ci < CI; ++ci) acc[ci] = fmaf(g[e], wp[ci], acc[ci]);
+              }
+            }
+          }
+        }
+      }
+    }
+  }
+  if (live) {
+    const int hi = i * sh + off_h, wi = j * sw + off_w;
+    float* o = gx + ((size_t)(n * H + hi) * W + wi) * CI;
+#pragma unroll
+    for (int ci = 0; ci < CI; ++ci) o[ci] = acc[ci] + (bias ? bias[ci] : 0.f);
+  }
+}
+
+}  // namespace
+
+// Returns 1 if the thin forward kernel took the call, 0 if the shape does not qualify, < 0 on error.
+int vg_try_fwd_thin(const vg_conv_geom* g, const float* x, const float* w, const float* bias, float* y, hipStream_t st) {
+  const int K = g->kh * g->kw * g->Ci;
+  if (g->Co > 4 || g->Ci % 4 != 0 || !vg_aligned16(x) || !vg_aligned16(w)) return 0;
+  const int M = g->N * g->Ho * g->Wo;
+  const bool wide = K >= 2048;
+  const int ppb = wide ? 1 : 4;
+  dim3 grid((unsigned)((M + ppb - 1) / ppb));
+#define THIN_FWD(CO_)                                                                                                  \
+  if (g->Co == CO_) {                                                                                                  \
+    if (wide)                                                                                                          \
+      hipLaunchKernelGGL((fwd_thin_kernel<CO_, 256>), grid, dim3(256), 0, st, x, w, bias, y, g->H, g->W, g->Ci, g->kw,  \
+                         g->Ho, g->Wo, g->sh, g->sw, g->ph, g->pw, M, K);                                             \
+    else                                                                                                               \
+      hipLaunchKernelGGL((fwd_thin_kernel<CO_, 64>), grid, dim3(256), 0, st, x, w, bias, y, g->H, g->W, g->Ci, g->kw,   \
+                         g->Ho, g->Wo, g->sh, g->sw, g->ph, g->pw, M, K);                                             \
+  }
+  THIN_FWD(1) THIN_FWD(2) THIN_FWD(3) THIN_FWD(4)
+#undef THIN_FWD
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return vg_fail(VG_ERR_LAUNCH, "vg_conv2d_fwd(thin): launch failed: %s", hipGetErrorString(e));
+  return 1;
+}
+
+static int thin_dgrad_chunk(const vg_conv_geom* g) {
+  // widest co chunk (multiple of 4) whose staged patch fits 64 KB of LDS; 0 if even 4 channels do not fit
+  const int nth = (g->kh + g->sh - 1) / g->sh, ntw = (g->kw + g->sw - 1) / g->sw;
+  const int pixels = (TI + nth - 1) * (TJ + ntw - 1);
+  for (int cc = 64; cc >= 4; cc /= 2)
+    if ((long long)pixels * (cc + 4) * 4 <= 64 * 1024) return cc;
+  return 0;
+}
+
+int vg_thin_dgrad_applies(const vg_conv_geom* g) {
+  return g->Ci <= 4 && g->Co % 4 == 0 && thin_dgrad_chunk(g) > 0 && g->sh * g->sw <= 65535;
+}
+
+int vg_try_dgrad_thin(const vg_conv_geom* g, const float* gy, const float* w, const float* bias, float* gx,
+                      hipStream_t st) {
+  if (!vg_thin_dgrad_applies(g) || !vg_aligned16(gy)) return 0;
+  int cc = thin_dgrad_chunk(g);
+  while (cc > g->Co && cc > 4) cc /= 2;
+  const int nth = (g->kh + g->sh - 1) / g->sh, ntw = (g->kw + g->sw - 1) / g->sw;
+  const size_t lds = (size_t)(TI + nth - 1) * (TJ + ntw - 1) * (cc + 4) * sizeof(float);
+  const int Hc = (g->H + g->sh - 1) / g->sh, Wc = (g->W + g->sw - 1) / g->sw;
+  const int itiles = (Hc + TI - 1) / TI, jtiles = (Wc + TJ - 1) / TJ;
+  dim3 grid((unsigned)(g->N * itiles * jtiles), 1, (unsigned)(g->sh * g->sw));
+#define THIN_DGRAD(CI_)                                                                                                 \
+  if (g->Ci == CI_)                                                                                                     \
+    hipLaunchKernelGGL((dgrad_thin_kernel<CI_>), grid, dim3(256), lds, st, gy, w, bias, gx, g->H, g->W, g->Co, g->kh,    \
+                       g->kw, g->Ho, g->Wo, g->sh, g->sw, g->ph, g->pw, cc, itiles, jtiles);
+  THIN_DGRAD(1) THIN_DGRAD(2) THIN_DGRAD(3) THIN_DGRAD(4)
+#undef THIN_DGRAD
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return vg_fail(VG_ERR_LAUNCH, "vg_conv2d_dgrad(thin): launch failed: %s", hipGetErrorString(e));
+  return 1;
+}

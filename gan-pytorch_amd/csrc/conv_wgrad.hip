@@ -6,7 +6,7 @@
 namespace {
 
 struct WgradPlan {
-  int M, Ncols, Ktot, bn, mtiles, ntiles, nsplit, kchunk;
+  int M, Ncols, Ktot, bm, bn, mtiles, ntiles, nsplit, kchunk;
 };
 
 WgradPlan wgrad_plan(const vg_conv_geom* g) {
@@ -15,11 +15,13 @@ WgradPlan wgrad_plan(const vg_conv_geom* g) {
   pl.Ncols = g->kh * g->kw * g->Ci;
   pl.Ktot = g->N * g->Ho * g->Wo;
   pl.bn = igemm_pick_bn(pl.Ncols);
-  pl.mtiles = (pl.M + 127) / 128;
+  pl.bm = (pl.M <= 64 && pl.bn != 32) ? 64 : 128;
+  pl.mtiles = (pl.M + pl.bm - 1) / pl.bm;
   pl.ntiles = (pl.Ncols + pl.bn - 1) / pl.bn;
   const int tiles = pl.mtiles * pl.ntiles;
-  // aim at ~3 blocks per CU, but keep at least 8 k-steps (256 pixels) per split
-  int want = (768 + tiles - 1) / tiles;
+  // aim at two blocks per CU (what the double-buffered tiles allow to be resident; every extra split costs a slab
+  // write + read), at least 8 k-steps (256 pixels) per split
+  int want = (512 + tiles / 2) / tiles;
   int max_split = pl.Ktot / 256;
   if (max_split < 1) max_split = 1;
   int ns = want < max_split ? want : max_split;
@@ -32,25 +34,55 @@ WgradPlan wgrad_plan(const vg_conv_geom* g) {
   return pl;
 }
 
+// out[i] = sum_z slabs[z][i].  A block owns 256 / LANES consecutive float4 columns; LANES threads per column each add
+// every LANES-th slab, then the lane partials are added in lane order through LDS (fixed order: deterministic).
+// Many slabs over a small tile (a stem layer's weight gradient: hundreds of splits of a 64 x 48 tile) would
+// otherwise be a serial chain per element.
+template <int LANES>
 __global__ void __launch_bounds__(256) slab_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ out,
-                                                          size_t count, int nsplit) {
-  const size_t stride = (size_t)gridDim.x * blockDim.x;
-  if ((count & 3) == 0) {
-    const size_t n4 = count >> 2;
-    const f32x4* s4 = reinterpret_cast<const f32x4*>(slabs);
-    f32x4* o4 = reinterpret_cast<f32x4*>(out);
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
-      f32x4 a = s4[i];
-      for (int z = 1; z < nsplit; ++z) a += s4[(size_t)z * n4 + i];
-      o4[i] = a;
-    }
-  } else {
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += stride) {
-      float a = slabs[i];
-      for (int z = 1; z < nsplit; ++z) a += slabs[(size_t)z * count + i];
-      out[i] = a;
+                                                          size_t count, int nsplit, int vec) {
+  __shared__ f32x4 red[256];
+  constexpr int COLS = 256 / LANES;
+  const int lane = threadIdx.x / COLS, col = threadIdx.x % COLS;
+  const size_t ncols = vec ? count >> 2 : count;
+  const size_t i = (size_t)blockIdx.x * COLS + col;
+  f32x4 a = {0.f, 0.f, 0.f, 0.f};
+  if (i < ncols) {
+    if (vec) {
+      const f32x4* s4 = reinterpret_cast<const f32x4*>(slabs);
+      for (int z = lane; z < nsplit; z += LANES) a += s4[(size_t)z * ncols + i];
+    } else {
+      for (int z = lane; z < nsplit; z += LANES) a[0] += slabs[(size_t)z * count + i];
     }
   }
+  if constexpr (LANES > 1) {
+    red[threadIdx.x] = a;
+    __syncthreads();
+    if (lane == 0) {
+#pragma unroll
+      for (int l = 1; l < LANES; ++l) a += red[l * COLS + col];
+    }
+  }
+  if (lane == 0 && i < ncols) {
+    if (vec) reinterpret_cast<f32x4*>(out)[i] = a;
+    else out[i] = a[0];
+  }
+}
+
+int launch_slab_reduce(const float* slabs, float* out, size_t count, int nsplit, hipStream_t st) {
+  const int vec = ((count & 3) == 0 && vg_aligned16(slabs) && vg_aligned16(out)) ? 1 : 0;
+  const size_t ncols = vec ? count >> 2 : count;
+  // enough lanes to keep ~2048+ threads busy on small tiles, one lane when the tile alone fills the chip
+  int lanes = 1;
+  while (lanes < 16 && lanes * 2 <= nsplit && ncols * lanes < 65536) lanes *= 2;
+#define SLAB_CASE(L_)                                                                                              \
+  if (lanes == L_) {                                                                                               \
+    const size_t blocks = (ncols + (256 / L_) - 1) / (256 / L_);                                                   \
+    hipLaunchKernelGGL((slab_reduce_kernel<L_>), dim3((unsigned)blocks), dim3(256), 0, st, slabs, out, count, nsplit, vec); \
+  }
+  SLAB_CASE(1) SLAB_CASE(2) SLAB_CASE(4) SLAB_CASE(8) SLAB_CASE(16)
+#undef SLAB_CASE
+  return 0;
 }
 
 }  // namespace
@@ -86,14 +118,11 @@ extern "C" int vg_conv2d_wgrad(const vg_conv_geom* g, const float* gy, const flo
   const int vb = (g->Ci % 4 == 0 && vg_aligned16(x)) ? 4 : 1;
   dim3 grid((unsigned)(pl.mtiles * pl.ntiles), 1, (unsigned)pl.nsplit);
   hipStream_t st = (hipStream_t)stream;
-  if (igemm_launch<MODE_WGRAD, true>(p, pl.bn, va, vb, grid, st) != 0)
+  if (igemm_launch<MODE_WGRAD, true>(p, pl.bm, pl.bn, va, vb, grid, st) != 0)
     return vg_fail(VG_ERR_INVALID, "vg_conv2d_wgrad: no kernel variant for bn=%d va=%d vb=%d", pl.bn, va, vb);
   VG_CHECK_LAUNCH("vg_conv2d_wgrad");
   if (pl.nsplit > 1) {
-    const size_t count = (size_t)pl.M * pl.Ncols;
-    const int blocks = vg_stream_grid((count + 3) / 4, 256);
-    hipLaunchKernelGGL(slab_reduce_kernel, dim3(blocks), dim3(256), 0, st, (const float*)workspace, gw, count,
-                       pl.nsplit);
+    launch_slab_reduce((const float*)workspace, gw, (size_t)pl.M * pl.Ncols, pl.nsplit, st);
     VG_CHECK_LAUNCH("vg_conv2d_wgrad(slab reduce)");
   }
   return VG_OK;

@@ -20,6 +20,13 @@
 
 enum { MODE_FWD = 0, MODE_DGRAD = 1, MODE_WGRAD = 2 };
 
+// A predicated-off lane reads these 16 bytes instead of branching around its load.
+static __device__ __attribute__((aligned(16))) float vg_zero_page[4] = {0.f, 0.f, 0.f, 0.f};  // never written
+
+// n / d for 0 <= n < 2^22 and small positive d, with inv = 1.0f / d: exact because (n + 0.5) / d is at least
+// 0.5 / d away from the next integer, far more than the float rounding of the product.
+__device__ __forceinline__ int vg_div_small(int n, float inv) { return (int)(((float)n + 0.5f) * inv); }
+
 struct IgemmParams {
   const float* A;     // fwd: x      dgrad: gy     wgrad: gy
   const float* B;     // fwd: w      dgrad: w      wgrad: x
@@ -45,9 +52,9 @@ __global__ void __launch_bounds__(256) igemm_kernel(const IgemmParams p) {
   constexpr bool B_IS_MC = B_MC || (MODE != MODE_FWD);
   static_assert(TM >= 1 && TN >= 1, "tile too small for the wave arrangement");
 
-  __shared__ __attribute__((aligned(16))) float smem[(BM + BN) * LDK];
-  float* As = smem;
-  float* Bs = smem + BM * LDK;
+  // two staging buffers: tile t+1 is written while tile t is being read, one barrier per k-step
+  constexpr int BUF = (BM + BN) * LDK;
+  __shared__ __attribute__((aligned(16))) float smem[2 * BUF];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wid = tid >> 6;
@@ -145,32 +152,73 @@ __global__ void __launch_bounds__(256) igemm_kernel(const IgemmParams p) {
     }
   }
 
+  // ---- k-walk state: the tile loaders are called for k-steps 0, 1, 2, ... in order and step this state by 32
+  // instead of re-deriving (tap, channel) / (image, row, column) with integer divisions every k-step ----------
+  int kpos = kbeg;                                    // first k of the tile the next load_tiles() call fetches
+  // A of fwd/dgrad: this thread's 4-wide k chunk -> (linear tap index, channel inside the tap)
+  int ak_c = 0, ak_t = 0;
+  const int a_cch = (MODE == MODE_FWD) ? p.Ci : p.Co;
+  const int a_steps = BK / a_cch, a_rem = BK - a_steps * a_cch;   // one k-step = a_steps whole taps + a_rem channels
+  const float inv_ntw = ntw > 0 ? 1.0f / (float)ntw : 0.f;
+  if constexpr (!A_MC && VA == 4) {
+    const int k4 = kbeg + 4 * (tid & 7);
+    ak_t = k4 / a_cch;
+    ak_c = k4 - ak_t * a_cch;
+  }
+  // dgrad weights B[k=(tap,co)][n]: one (linear tap, co) per k row owned by this thread
+  int bk_co[(MODE == MODE_DGRAD) ? PB : 1], bk_t[(MODE == MODE_DGRAD) ? PB : 1];
+  if constexpr (MODE == MODE_DGRAD) {
+#pragma unroll
+    for (int i = 0; i < PB; ++i) {
+      const int k = kbeg + tid / TPRB + RPB * i;
+      bk_t[i] = k / p.Co;
+      bk_co[i] = k - bk_t[i] * p.Co;
+    }
+  }
+  // wgrad x-window B[k=pixel][n]: one output pixel (image*Ho + ho, wo) per k row owned by this thread
+  int bp_row[(MODE == MODE_WGRAD) ? PB : 1], bp_wo[(MODE == MODE_WGRAD) ? PB : 1];
+  const int w_steps = (MODE == MODE_WGRAD) ? BK / p.Wo : 0, w_rem = (MODE == MODE_WGRAD) ? BK - w_steps * p.Wo : 0;
+  const float inv_ho = 1.0f / (float)p.Ho;
+  if constexpr (MODE == MODE_WGRAD) {
+#pragma unroll
+    for (int i = 0; i < PB; ++i) {
+      const int pix = kbeg + tid / TPRB + RPB * i;
+      bp_row[i] = pix / p.Wo;
+      bp_wo[i] = pix - bp_row[i] * p.Wo;
+    }
+  }
+
   f32x4 ra[A_MC ? PA : RA];
   f32x4 rb[B_IS_MC ? PB : RB];
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 
-  auto load_tiles = [&](int kt) {
-    const int kb = kbeg + kt * BK;
+  // Predicated 16-byte load without a branch and without touching the loaded value: an invalid lane reads the
+  // zero page, so a tile's loads are one straight-line sequence and nothing waits on them until the LDS store.
+  auto ld4 = [&](const float* base, size_t off, bool ok) -> f32x4 {
+    const float* ptr = ok ? base + off : vg_zero_page;
+    return *reinterpret_cast<const f32x4*>(ptr);
+  };
+
+  auto load_tiles = [&]() {
+    const int kb = kpos;
     // ---------------- A ----------------
     if constexpr (!A_MC) {
       const int k4 = kb + 4 * (tid & 7);
       const int Cch = (MODE == MODE_FWD) ? p.Ci : p.Co;
       if constexpr (VA == 4) {
         const bool kvalid = k4 < kend;
-        const int tap = k4 / Cch, c = k4 - tap * Cch;
-        const int ta = tap / ntw, tb = tap - ta * ntw;
+        const int ak_ta = vg_div_small(ak_t, inv_ntw), ak_tb = ak_t - ak_ta * ntw;
 #pragma unroll
         for (int i = 0; i < RA; ++i) {
-          f32x4 v = {0.f, 0.f, 0.f, 0.f};
           if constexpr (MODE == MODE_FWD) {
-            const int hi = a_h[i] + ta, wi = a_w[i] + tb;
-            if (kvalid && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W)
-              v = *reinterpret_cast<const f32x4*>(p.A + (size_t)(a_img[i] + hi * p.W + wi) * p.Ci + c);
+            const int hi = a_h[i] + ak_ta, wi = a_w[i] + ak_tb;
+            const bool ok = kvalid && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
+            ra[i] = ld4(p.A, (size_t)(a_img[i] + hi * p.W + wi) * p.Ci + ak_c, ok);
           } else {
-            const int ho = a_h[i] - ta, wo = a_w[i] - tb;
-            if (kvalid && (unsigned)ho < (unsigned)p.Ho && (unsigned)wo < (unsigned)p.Wo)
-              v = *reinterpret_cast<const f32x4*>(p.A + (size_t)(a_img[i] + ho * p.Wo + wo) * p.Co + c);
+            const int ho = a_h[i] - ak_ta, wo = a_w[i] - ak_tb;
+            const bool ok = kvalid && (unsigned)ho < (unsigned)p.Ho && (unsigned)wo < (unsigned)p.Wo;
+            ra[i] = ld4(p.A, (size_t)(a_img[i] + ho * p.Wo + wo) * p.Co + ak_c, ok);
           }
-          ra[i] = v;
         }
       } else {
         int ta[4], tb[4], c[4];
@@ -186,7 +234,7 @@ __global__ void __launch_bounds__(256) igemm_kernel(const IgemmParams p) {
         }
 #pragma unroll
         for (int i = 0; i < RA; ++i) {
-          f32x4 v = {0.f, 0.f, 0.f, 0.f};
+          f32x4 v = zero4;
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             if constexpr (MODE == MODE_FWD) {
@@ -208,17 +256,17 @@ __global__ void __launch_bounds__(256) igemm_kernel(const IgemmParams p) {
 #pragma unroll
       for (int i = 0; i < PA; ++i) {
         const int pix = kb + tid / TPRA + RPA * i;
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (pix < kend) {
-          if constexpr (VA == 4) {
-            if (m4 < p.Co) v = *reinterpret_cast<const f32x4*>(p.A + (size_t)pix * p.Co + m4);
-          } else {
+        if constexpr (VA == 4) {
+          ra[i] = ld4(p.A, (size_t)pix * p.Co + m4, pix < kend && m4 < p.Co);
+        } else {
+          f32x4 v = zero4;
+          if (pix < kend) {
 #pragma unroll
             for (int e = 0; e < 4; ++e)
               if (m4 + e < p.Co) v[e] = p.A[(size_t)pix * p.Co + m4 + e];
           }
+          ra[i] = v;
         }
-        ra[i] = v;
       }
     }
     // ---------------- B ----------------
@@ -228,86 +276,111 @@ __global__ void __launch_bounds__(256) igemm_kernel(const IgemmParams p) {
 #pragma unroll
       for (int i = 0; i < RB; ++i) {
         const int n = n0 + (tid >> 3) + 32 * i;
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (n < p.Ncols) {
-          if constexpr (VB == 4) {
-            if (k4 < kend) v = *reinterpret_cast<const f32x4*>(p.B + (size_t)n * Ktot + k4);
-          } else {
+        if constexpr (VB == 4) {
+          rb[i] = ld4(p.B, (size_t)n * Ktot + k4, n < p.Ncols && k4 < kend);
+        } else {
+          f32x4 v = zero4;
+          if (n < p.Ncols) {
 #pragma unroll
             for (int e = 0; e < 4; ++e)
               if (k4 + e < kend) v[e] = p.B[(size_t)n * Ktot + k4 + e];
           }
+          rb[i] = v;
         }
-        rb[i] = v;
       }
     } else if constexpr (MODE == MODE_FWD) {
       // plain GEMM operand B[k][n] (row stride Ncols)
 #pragma unroll
       for (int i = 0; i < PB; ++i) {
         const int k = kb + tid / TPRB + RPB * i;
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (k < kend) {
-          if constexpr (VB == 4) {
-            if (bn4 < p.Ncols) v = *reinterpret_cast<const f32x4*>(p.B + (size_t)k * p.Ncols + bn4);
-          } else {
+        if constexpr (VB == 4) {
+          rb[i] = ld4(p.B, (size_t)k * p.Ncols + bn4, k < kend && bn4 < p.Ncols);
+        } else {
+          f32x4 v = zero4;
+          if (k < kend) {
 #pragma unroll
             for (int e = 0; e < 4; ++e)
               if (bn4 + e < p.Ncols) v[e] = p.B[(size_t)k * p.Ncols + bn4 + e];
           }
+          rb[i] = v;
         }
-        rb[i] = v;
       }
     } else if constexpr (MODE == MODE_DGRAD) {
       // weights w[co][kh][kw][ci] read as B[k=(tap,co)][n=ci]
 #pragma unroll
       for (int i = 0; i < PB; ++i) {
         const int k = kb + tid / TPRB + RPB * i;
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (k < kend) {
-          const int tap = k / p.Co, co = k - tap * p.Co;
-          const int ta = tap / ntw, tb = tap - ta * ntw;
-          const int kh = cls_h + p.sh * ta, kw = cls_w + p.sw * tb;
-          const size_t base = ((size_t)(co * p.KH + kh) * p.KW + kw) * p.Ci;
-          if constexpr (VB == 4) {
-            if (bn4 < p.Ncols) v = *reinterpret_cast<const f32x4*>(p.B + base + bn4);
-          } else {
+        const int bta = vg_div_small(bk_t[i], inv_ntw), btb = bk_t[i] - bta * ntw;
+        const int kh = cls_h + p.sh * bta, kw = cls_w + p.sw * btb;
+        const size_t base = ((size_t)(bk_co[i] * p.KH + kh) * p.KW + kw) * p.Ci;
+        if constexpr (VB == 4) {
+          rb[i] = ld4(p.B, base + bn4, k < kend && bn4 < p.Ncols);
+        } else {
+          f32x4 v = zero4;
+          if (k < kend) {
 #pragma unroll
             for (int e = 0; e < 4; ++e)
               if (bn4 + e < p.Ncols) v[e] = p.B[base + bn4 + e];
           }
+          rb[i] = v;
         }
-        rb[i] = v;
       }
     } else {
       // wgrad B = x window, tile [k=pixel][n=(kh,kw,ci)]
-      const int hw = p.Ho * p.Wo;
 #pragma unroll
       for (int i = 0; i < PB; ++i) {
         const int pix = kb + tid / TPRB + RPB * i;
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (pix < kend) {
-          const int n = pix / hw, rem = pix - n * hw;
-          const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
-          const int hb = ho * p.sh - p.ph, wb = wo * p.sw - p.pw;
-          if constexpr (VB == 4) {
-            const int hi = hb + b_ta[0], wi = wb + b_tb[0];
-            if ((unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W)
-              v = *reinterpret_cast<const f32x4*>(p.B + (size_t)((n * p.H + hi) * p.W + wi) * p.Ci + b_ci[0]);
-          } else {
+        const int bpn = vg_div_small(bp_row[i], inv_ho), bpho = bp_row[i] - bpn * p.Ho;
+        const int hb = bpho * p.sh - p.ph, wb = bp_wo[i] * p.sw - p.pw;
+        if constexpr (VB == 4) {
+          const int hi = hb + b_ta[0], wi = wb + b_tb[0];
+          const bool ok = pix < kend && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
+          rb[i] = ld4(p.B, (size_t)((bpn * p.H + hi) * p.W + wi) * p.Ci + b_ci[0], ok);
+        } else {
+          f32x4 v = zero4;
+          if (pix < kend) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
               const int hi = hb + b_ta[e], wi = wb + b_tb[e];
               if ((unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W)
-                v[e] = p.B[(size_t)((n * p.H + hi) * p.W + wi) * p.Ci + b_ci[e]];
+                v[e] = p.B[(size_t)((bpn * p.H + hi) * p.W + wi) * p.Ci + b_ci[e]];
             }
           }
+          rb[i] = v;
         }
-        rb[i] = v;
+      }
+    }
+    // ---------------- advance the k-walk by one tile (branch-free) ----------------
+    kpos += BK;
+    if constexpr (!A_MC && VA == 4) {
+      ak_c += a_rem;
+      const int carry = ak_c >= a_cch ? 1 : 0;
+      ak_c -= carry ? a_cch : 0;
+      ak_t += a_steps + carry;
+    }
+    if constexpr (MODE == MODE_DGRAD) {
+#pragma unroll
+      for (int i = 0; i < PB; ++i) {
+        bk_co[i] += a_rem;
+        const int carry = bk_co[i] >= a_cch ? 1 : 0;
+        bk_co[i] -= carry ? a_cch : 0;
+        bk_t[i] += a_steps + carry;
+      }
+    }
+    if constexpr (MODE == MODE_WGRAD) {
+#pragma unroll
+      for (int i = 0; i < PB; ++i) {
+        bp_wo[i] += w_rem;
+        const int carry = bp_wo[i] >= p.Wo ? 1 : 0;
+        bp_wo[i] -= carry ? p.Wo : 0;
+        bp_row[i] += w_steps + carry;
       }
     }
   };
 
-  auto store_tiles = [&]() {
+  auto store_tiles = [&](int buf) {
+    float* As = smem + buf * BUF;
+    float* Bs = As + BM * LDK;
     if constexpr (!A_MC) {
 #pragma unroll
       for (int i = 0; i < RA; ++i)
@@ -336,53 +409,66 @@ __global__ void __launch_bounds__(256) igemm_kernel(const IgemmParams p) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.f;
 
+  // one 8-deep slice of the current tile: fragment reads, then 4 * TM * TN MFMAs
+  auto mma_slice = [&](const float* As, const float* Bs, int s) {
+    f32x4 af[TM], bf[TN];
+#pragma unroll
+    for (int mi = 0; mi < TM; ++mi) {
+      const int row = (wm * TM + mi) * 32 + r;
+      if constexpr (!A_MC) {
+        af[mi] = *reinterpret_cast<const f32x4*>(&As[row * LDK + 8 * s + 4 * h]);
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) af[mi][j] = As[(8 * s + 4 * h + j) * BM + row];
+      }
+    }
+#pragma unroll
+    for (int ni = 0; ni < TN; ++ni) {
+      const int col = (wn * TN + ni) * 32 + r;
+      if constexpr (!B_IS_MC) {
+        bf[ni] = *reinterpret_cast<const f32x4*>(&Bs[col * LDK + 8 * s + 4 * h]);
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bf[ni][j] = Bs[(8 * s + 4 * h + j) * BN + col];
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < TN; ++ni)
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mi][j], bf[ni][j], acc[mi][ni], 0, 0, 0);
+  };
+
+  // One k-step on buffer `buf`: the next tile's global loads are issued first and stay in flight under the first
+  // half of the MFMAs; they are written to the other buffer (last read one k-step ago, behind a barrier) before
+  // the second half, so the store latency hides under MFMAs too.
+  auto k_step = [&](int kt, int buf) {
+    const bool more = kt + 1 < nk;
+    if (more) load_tiles();
+    const float* As = smem + buf * BUF;
+    const float* Bs = As + BM * LDK;
+    mma_slice(As, Bs, 0);
+    mma_slice(As, Bs, 1);
+    if (more) store_tiles(buf ^ 1);
+    mma_slice(As, Bs, 2);
+    mma_slice(As, Bs, 3);
+    __syncthreads();
+  };
+
   if (nk > 0) {
-    load_tiles(0);
-    store_tiles();
+    load_tiles();
+    store_tiles(0);
   }
   __syncthreads();
 
-  for (int kt = 0; kt < nk; ++kt) {
-    if (kt + 1 < nk) load_tiles(kt + 1);  // global loads stay in flight under the MFMAs below
-
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      f32x4 af[TM], bf[TN];
-#pragma unroll
-      for (int mi = 0; mi < TM; ++mi) {
-        const int row = (wm * TM + mi) * 32 + r;
-        if constexpr (!A_MC) {
-          af[mi] = *reinterpret_cast<const f32x4*>(&As[row * LDK + 8 * s + 4 * h]);
-        } else {
-#pragma unroll
-          for (int j = 0; j < 4; ++j) af[mi][j] = As[(8 * s + 4 * h + j) * BM + row];
-        }
-      }
-#pragma unroll
-      for (int ni = 0; ni < TN; ++ni) {
-        const int col = (wn * TN + ni) * 32 + r;
-        if constexpr (!B_IS_MC) {
-          bf[ni] = *reinterpret_cast<const f32x4*>(&Bs[col * LDK + 8 * s + 4 * h]);
-        } else {
-#pragma unroll
-          for (int j = 0; j < 4; ++j) bf[ni][j] = Bs[(8 * s + 4 * h + j) * BN + col];
-        }
-      }
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int mi = 0; mi < TM; ++mi)
-#pragma unroll
-          for (int ni = 0; ni < TN; ++ni)
-            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mi][j], bf[ni][j], acc[mi][ni], 0, 0, 0);
-    }
-
-    __syncthreads();
-    if (kt + 1 < nk) {
-      store_tiles();
-      __syncthreads();
-    }
+  int kt = 0;
+  for (; kt + 1 < nk; kt += 2) {
+    k_step(kt, 0);
+    k_step(kt + 1, 1);
   }
+  if (kt < nk) k_step(kt, 0);
 
   // ---- epilogue: lane holds column (lane&31) and rows (e&3)+8*(e>>2)+4*(lane>>5) of each 32x32 tile ----
   float* outp = p.out;
@@ -417,28 +503,33 @@ __global__ void __launch_bounds__(256) igemm_kernel(const IgemmParams p) {
   }
 }
 
-// Launch one (BN, VA, VB) variant chosen at run time. BM is 128; the wave arrangement follows BN.
+// Launch one (BM, BN, VA, VB) variant chosen at run time; the wave arrangement follows the tile.
 template <int MODE, bool B_MC>
-static inline int igemm_launch(const IgemmParams& p, int bn, int va, int vb, dim3 grid, hipStream_t st) {
-#define IGEMM_CASE(BN_, WM_, VA_, VB_)                                                             \
-  if (bn == BN_ && va == VA_ && vb == VB_) {                                                       \
-    hipLaunchKernelGGL((igemm_kernel<MODE, 128, BN_, WM_, B_MC, VA_, VB_>), grid, dim3(256), 0, st, p); \
-    return 0;                                                                                      \
+static inline int igemm_launch(const IgemmParams& p, int bm, int bn, int va, int vb, dim3 grid, hipStream_t st) {
+#define IGEMM_CASE(BM_, BN_, WM_, VA_, VB_)                                                          \
+  if (bm == BM_ && bn == BN_ && va == VA_ && vb == VB_) {                                            \
+    hipLaunchKernelGGL((igemm_kernel<MODE, BM_, BN_, WM_, B_MC, VA_, VB_>), grid, dim3(256), 0, st, p); \
+    return 0;                                                                                        \
   }
-  IGEMM_CASE(128, 2, 4, 4)
-  IGEMM_CASE(128, 2, 4, 1)
-  IGEMM_CASE(128, 2, 1, 4)
-  IGEMM_CASE(128, 2, 1, 1)
-  IGEMM_CASE(64, 2, 4, 4)
-  IGEMM_CASE(64, 2, 4, 1)
-  IGEMM_CASE(64, 2, 1, 4)
-  IGEMM_CASE(64, 2, 1, 1)
-  IGEMM_CASE(32, 4, 4, 4)
-  IGEMM_CASE(32, 4, 4, 1)
-  IGEMM_CASE(32, 4, 1, 4)
-  IGEMM_CASE(32, 4, 1, 1)
+#define IGEMM_TILE(BM_, BN_, WM_) \
+  IGEMM_CASE(BM_, BN_, WM_, 4, 4) IGEMM_CASE(BM_, BN_, WM_, 4, 1) IGEMM_CASE(BM_, BN_, WM_, 1, 4) IGEMM_CASE(BM_, BN_, WM_, 1, 1)
+  IGEMM_TILE(128, 128, 2)
+  IGEMM_TILE(128, 64, 2)
+  IGEMM_TILE(128, 32, 4)
+  IGEMM_TILE(64, 128, 2)
+  IGEMM_TILE(64, 64, 2)
+#undef IGEMM_TILE
 #undef IGEMM_CASE
   return -1;
+}
+
+static inline int igemm_waves_m(int bm, int bn) { return (bm == 128 && bn == 32) ? 4 : 2; }
+
+// Rows per tile: 128 unless that leaves most of the 256 CUs without a block and a 64-row tile exists for this BN.
+static inline int igemm_pick_bm(long long rows, int ntiles, int zdim, int bn) {
+  if (bn == 32 || rows <= 64) return rows <= 64 && bn != 32 ? 64 : 128;
+  const long long blocks128 = ((rows + 127) / 128) * ntiles * zdim;
+  return blocks128 < 200 ? 64 : 128;
 }
 
 static inline int igemm_pick_bn(int ncols) { return ncols > 64 ? 128 : (ncols > 32 ? 64 : 32); }

@@ -58,17 +58,18 @@ __global__ void __launch_bounds__(256) colreduce_partial(F f, int M, int C, int 
   }
 }
 
-// out[v][c] = sum_b partial[v][b][c]; 64 channels x 4 block-lanes per workgroup, fixed summation order.
+// out[v][c] = sum_b partial[v][b][c]; 16 channels x 16 block-lanes per workgroup, fixed summation order.
 template <int NV>
 __global__ void __launch_bounds__(256) colreduce_final(const float* partial, int nblk, int C, float* out) {
   __shared__ float red[NV * 256];
-  const int c = blockIdx.x * 64 + (threadIdx.x & 63);
-  const int q = threadIdx.x >> 6;
+  const int cl = threadIdx.x & 15, q = threadIdx.x >> 4;
+  const int c = blockIdx.x * 16 + cl;
   float acc[NV];
 #pragma unroll
   for (int v = 0; v < NV; ++v) acc[v] = 0.f;
   if (c < C) {
-    for (int b = q; b < nblk; b += 4) {
+#pragma unroll 4
+    for (int b = q; b < nblk; b += 16) {
 #pragma unroll
       for (int v = 0; v < NV; ++v) acc[v] += partial[((size_t)v * nblk + b) * C + c];
     }
@@ -79,8 +80,11 @@ __global__ void __launch_bounds__(256) colreduce_final(const float* partial, int
   if (q == 0 && c < C) {
 #pragma unroll
     for (int v = 0; v < NV; ++v) {
-      const float* rr = red + v * 256 + (threadIdx.x & 63);
-      out[(size_t)v * C + c] = (rr[0] + rr[64]) + (rr[128] + rr[192]);
+      const float* rr = red + v * 256 + cl;
+      float s = 0.f;
+#pragma unroll
+      for (int j = 0; j < 16; ++j) s += rr[16 * j];
+      out[(size_t)v * C + c] = s;
     }
   }
 }
@@ -98,7 +102,7 @@ int run_colreduce(const char* who, F f, int M, int C, bool vec_ok, float* out, v
   else
     hipLaunchKernelGGL((colreduce_partial<NV, 1, F>), dim3(nb), dim3(256), 0, st, f, M, C, rpb, partial);
   VG_CHECK_LAUNCH(who);
-  hipLaunchKernelGGL((colreduce_final<NV>), dim3((C + 63) / 64), dim3(256), 0, st, (const float*)partial, nb, C, out);
+  hipLaunchKernelGGL((colreduce_final<NV>), dim3((C + 15) / 16), dim3(256), 0, st, (const float*)partial, nb, C, out);
   VG_CHECK_LAUNCH(who);
   return VG_OK;
 }

@@ -149,6 +149,21 @@ class ConvTimer:
 conv_timer = None   # a ConvTimer while a benchmark wants per-kernel durations, else None
 
 
+class inputs_only:
+    """While active, backward passes compute gradients with respect to activations only (no weight / bias
+    gradients).  Used around `torch.autograd.grad(outputs, inputs=<activation>)` calls such as the gradient penalty's
+    first-order pass: custom autograd Functions cannot see which of their gradients that call will keep, and the
+    unused weight gradients there cost as much as a critic forward."""
+    active = False
+
+    def __enter__(self):
+        self.prev = inputs_only.active
+        inputs_only.active = True
+
+    def __exit__(self, *exc):
+        inputs_only.active = self.prev
+
+
 def _launch_conv(mode, g, fn):
     if conv_timer is None:
         fn()
@@ -232,9 +247,10 @@ class ConvFwdFn(Function):
     def backward(ctx, gy):
         x, w = ctx.saved_tensors
         g = ctx.g
+        params = not inputs_only.active
         gx = ConvDgradFn.apply(gy, w, None, g) if ctx.needs_input_grad[0] else None
-        gw = ConvWgradFn.apply(gy, x, g, tuple(w.shape)) if ctx.needs_input_grad[1] else None
-        gb = ColSumFn.apply(gy) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
+        gw = ConvWgradFn.apply(gy, x, g, tuple(w.shape)) if (params and ctx.needs_input_grad[1]) else None
+        gb = ColSumFn.apply(gy) if (params and ctx.has_bias and ctx.needs_input_grad[2]) else None
         return gx, gw, gb, None
 
 
@@ -252,9 +268,10 @@ class ConvDgradFn(Function):
     def backward(ctx, ggx):
         gy, w = ctx.saved_tensors
         g = ctx.g
+        params = not inputs_only.active
         d_gy = ConvFwdFn.apply(ggx, w, None, g) if ctx.needs_input_grad[0] else None
-        d_w = ConvWgradFn.apply(gy, ggx, g, tuple(w.shape)) if ctx.needs_input_grad[1] else None
-        d_b = ColSumFn.apply(ggx) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
+        d_w = ConvWgradFn.apply(gy, ggx, g, tuple(w.shape)) if (params and ctx.needs_input_grad[1]) else None
+        d_b = ColSumFn.apply(ggx) if (params and ctx.has_bias and ctx.needs_input_grad[2]) else None
         return d_gy, d_w, d_b, None
 
 

@@ -144,8 +144,9 @@ class _PenaltyMixin:
         d_interpolates = self.adversariat(interpolates)
         ones = torch.empty_like(d_interpolates)
         ops.fill_(ones, 1.0)
-        gradients = torch.autograd.grad(outputs=d_interpolates, inputs=interpolates, grad_outputs=ones,
-                                        create_graph=True, retain_graph=True, only_inputs=True)[0]
+        with ops.inputs_only():
+            gradients = torch.autograd.grad(outputs=d_interpolates, inputs=interpolates, grad_outputs=ones,
+                                            create_graph=True, retain_graph=True, only_inputs=True)[0]
         return ops.gradient_penalty(gradients)
 
 
