@@ -94,8 +94,9 @@ extern "C" size_t vg_conv2d_wgrad_workspace_bytes(const vg_conv_geom* g) {
   return (size_t)pl.nsplit * pl.M * pl.Ncols * sizeof(float);
 }
 
-extern "C" int vg_conv2d_wgrad(const vg_conv_geom* g, const float* gy, const float* x, float* gw, void* workspace,
-                               size_t workspace_bytes, void* stream) {
+// Phase 1: the contraction. With more than one split the per-split slabs land in `workspace`, otherwise `gw` is final.
+extern "C" int vg_conv2d_wgrad_partial(const vg_conv_geom* g, const float* gy, const float* x, float* gw, void* workspace,
+                                       size_t workspace_bytes, void* stream) {
   if (int e = vg_check_geom(g, "vg_conv2d_wgrad")) return e;
   VG_REQUIRE(gy && x && gw, "vg_conv2d_wgrad: null tensor pointer");
   const WgradPlan pl = wgrad_plan(g);
@@ -117,13 +118,25 @@ extern "C" int vg_conv2d_wgrad(const vg_conv_geom* g, const float* gy, const flo
   const int va = (g->Co % 4 == 0 && vg_aligned16(gy)) ? 4 : 1;
   const int vb = (g->Ci % 4 == 0 && vg_aligned16(x)) ? 4 : 1;
   dim3 grid((unsigned)(pl.mtiles * pl.ntiles), 1, (unsigned)pl.nsplit);
-  hipStream_t st = (hipStream_t)stream;
-  if (igemm_launch<MODE_WGRAD, true>(p, pl.bm, pl.bn, va, vb, grid, st) != 0)
+  if (igemm_launch<MODE_WGRAD, true>(p, pl.bm, pl.bn, va, vb, grid, (hipStream_t)stream) != 0)
     return vg_fail(VG_ERR_INVALID, "vg_conv2d_wgrad: no kernel variant for bn=%d va=%d vb=%d", pl.bn, va, vb);
   VG_CHECK_LAUNCH("vg_conv2d_wgrad");
-  if (pl.nsplit > 1) {
-    launch_slab_reduce((const float*)workspace, gw, (size_t)pl.M * pl.Ncols, pl.nsplit, st);
-    VG_CHECK_LAUNCH("vg_conv2d_wgrad(slab reduce)");
-  }
   return VG_OK;
+}
+
+// Phase 2: add the slabs (no-op when the plan has a single split).
+extern "C" int vg_conv2d_wgrad_reduce(const vg_conv_geom* g, float* gw, const void* workspace, void* stream) {
+  if (int e = vg_check_geom(g, "vg_conv2d_wgrad_reduce")) return e;
+  const WgradPlan pl = wgrad_plan(g);
+  if (pl.nsplit <= 1) return VG_OK;
+  VG_REQUIRE(gw && workspace, "vg_conv2d_wgrad_reduce: null pointer");
+  launch_slab_reduce((const float*)workspace, gw, (size_t)pl.M * pl.Ncols, pl.nsplit, (hipStream_t)stream);
+  VG_CHECK_LAUNCH("vg_conv2d_wgrad(slab reduce)");
+  return VG_OK;
+}
+
+extern "C" int vg_conv2d_wgrad(const vg_conv_geom* g, const float* gy, const float* x, float* gw, void* workspace,
+                               size_t workspace_bytes, void* stream) {
+  if (int e = vg_conv2d_wgrad_partial(g, gy, x, gw, workspace, workspace_bytes, stream)) return e;
+  return vg_conv2d_wgrad_reduce(g, gw, workspace, stream);
 }

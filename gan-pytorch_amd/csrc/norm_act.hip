@@ -126,6 +126,29 @@ __device__ __forceinline__ void stv(float* p, const float (&v)[VEC]) {
   }
 }
 
+// ---- elementwise -----------------------------------------------------------------------------------
+__device__ __forceinline__ float act_apply(float v, int act, float slope) {
+  switch (act) {
+    case VG_ACT_RELU: return v > 0.f ? v : 0.f;
+    case VG_ACT_LRELU: return v > 0.f ? v : v * slope;
+    case VG_ACT_TANH: return tanhf(v);
+    case VG_ACT_SIGMOID: return 1.0f / (1.0f + expf(-v));
+    default: return v;
+  }
+}
+
+// gx factor; `ref` = forward input (relu/lrelu) or forward output (tanh/sigmoid)
+__device__ __forceinline__ float act_grad(float ref, int act, float slope) {
+  switch (act) {
+    case VG_ACT_RELU: return ref > 0.f ? 1.f : 0.f;
+    case VG_ACT_LRELU: return ref > 0.f ? 1.f : slope;
+    case VG_ACT_TANH: return 1.f - ref * ref;
+    case VG_ACT_SIGMOID: return ref * (1.f - ref);
+    default: return 1.f;
+  }
+}
+
+
 // ---- functors -------------------------------------------------------------------------------------
 struct SumF {  // colsum
   const float* x;
@@ -154,12 +177,20 @@ struct ShiftedMomentsF {  // sums of (x - x[0][c]) and its square
   }
 };
 
-struct BnBwdF {  // sum gy, sum gy*xhat
-  const float *gy, *x, *mean, *invstd;
+struct BnBwdF {  // sum g, sum g*xhat with g = gy * act'(act_out) when an activation is fused behind the norm
+  const float *gy, *x, *mean, *invstd, *act_out;
+  int act;
+  float slope;
   template <int VEC>
   __device__ void eval(size_t off, int c, float (&acc)[2][VEC]) const {
     float g[VEC], a[VEC], mu[VEC], r[VEC];
     ldv<VEC>(gy + off, g);
+    if (act_out) {
+      float y[VEC];
+      ldv<VEC>(act_out + off, y);
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) g[e] *= act_grad(y[e], act, slope);
+    }
     ldv<VEC>(x + off, a);
     ldv<VEC>(mean + c, mu);
     ldv<VEC>(invstd + c, r);
@@ -172,12 +203,20 @@ struct BnBwdF {  // sum gy, sum gy*xhat
   }
 };
 
-struct BnDbwdF {  // sum gy, sum gy*xhat, sum u, sum u*xhat, sum u*gy
-  const float *gy, *x, *u, *mean, *invstd;
+struct BnDbwdF {  // sum g, sum g*xhat, sum u, sum u*xhat, sum u*g   (g as in BnBwdF)
+  const float *gy, *x, *u, *mean, *invstd, *act_out;
+  int act;
+  float slope;
   template <int VEC>
   __device__ void eval(size_t off, int c, float (&acc)[5][VEC]) const {
     float g[VEC], a[VEC], uu[VEC], mu[VEC], r[VEC];
     ldv<VEC>(gy + off, g);
+    if (act_out) {
+      float y[VEC];
+      ldv<VEC>(act_out + off, y);
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) g[e] *= act_grad(y[e], act, slope);
+    }
     ldv<VEC>(x + off, a);
     ldv<VEC>(u + off, uu);
     ldv<VEC>(mean + c, mu);
@@ -220,28 +259,6 @@ __global__ void __launch_bounds__(256) invstd_kernel(const float* var, float* in
   if (c < C) invstd[c] = 1.0f / sqrtf(var[c] + eps);
 }
 
-// ---- elementwise -----------------------------------------------------------------------------------
-__device__ __forceinline__ float act_apply(float v, int act, float slope) {
-  switch (act) {
-    case VG_ACT_RELU: return v > 0.f ? v : 0.f;
-    case VG_ACT_LRELU: return v > 0.f ? v : v * slope;
-    case VG_ACT_TANH: return tanhf(v);
-    case VG_ACT_SIGMOID: return 1.0f / (1.0f + expf(-v));
-    default: return v;
-  }
-}
-
-// gx factor; `ref` = forward input (relu/lrelu) or forward output (tanh/sigmoid)
-__device__ __forceinline__ float act_grad(float ref, int act, float slope) {
-  switch (act) {
-    case VG_ACT_RELU: return ref > 0.f ? 1.f : 0.f;
-    case VG_ACT_LRELU: return ref > 0.f ? 1.f : slope;
-    case VG_ACT_TANH: return 1.f - ref * ref;
-    case VG_ACT_SIGMOID: return ref * (1.f - ref);
-    default: return 1.f;
-  }
-}
-
 template <int VEC>
 __global__ void __launch_bounds__(256) bn_apply_kernel(const float* __restrict__ x, const float* __restrict__ mean,
                                                        const float* __restrict__ invstd, const float* __restrict__ gamma,
@@ -272,13 +289,20 @@ template <int VEC>
 __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const float* __restrict__ gy, const float* __restrict__ x,
                                                            const float* __restrict__ mean, const float* __restrict__ invstd,
                                                            const float* __restrict__ gamma, const float* __restrict__ sums,
-                                                           float* __restrict__ gx, size_t nvec, int C, float inv_n) {
+                                                           float* __restrict__ gx, size_t nvec, int C, float inv_n,
+                                                           const float* __restrict__ act_out, int act, float slope) {
   const int CG = C / VEC;
   const size_t stride = (size_t)gridDim.x * blockDim.x;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += stride) {
     const int c = (int)(i % CG) * VEC;
     float g[VEC], a[VEC], mu[VEC], r[VEC], ga[VEC], sg[VEC], sgx[VEC], o[VEC];
     ldv<VEC>(gy + i * VEC, g);
+    if (act_out) {
+      float y[VEC];
+      ldv<VEC>(act_out + i * VEC, y);
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) g[e] *= act_grad(y[e], act, slope);
+    }
     ldv<VEC>(x + i * VEC, a);
     ldv<VEC>(mean + c, mu);
     ldv<VEC>(invstd + c, r);
@@ -319,14 +343,25 @@ __global__ void __launch_bounds__(256) bn_dbwd_apply_kernel(
     const float* __restrict__ gy, const float* __restrict__ x, const float* __restrict__ u, const float* __restrict__ v,
     const float* __restrict__ w, const float* __restrict__ mean, const float* __restrict__ invstd,
     const float* __restrict__ gamma, const float* __restrict__ sums5, float* __restrict__ d_gy, float* __restrict__ d_x,
-    size_t nvec, int C, float inv_n) {
+    size_t nvec, int C, float inv_n, const float* __restrict__ act_out, int act, float slope) {
   const int CG = C / VEC;
   const size_t stride = (size_t)gridDim.x * blockDim.x;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += stride) {
     const int c = (int)(i % CG) * VEC;
     float g[VEC], a[VEC], uu[VEC], mu[VEC], r[VEC], ga[VEC], vv[VEC], ww[VEC];
-    float s0[VEC], s1[VEC], s2[VEC], s3[VEC], s4[VEC], o1[VEC], o2[VEC];
+    float s0[VEC], s1[VEC], s2[VEC], s3[VEC], s4[VEC], o1[VEC], o2[VEC], mk[VEC];
     ldv<VEC>(gy + i * VEC, g);
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) mk[e] = 1.f;
+    if (act_out) {
+      float y[VEC];
+      ldv<VEC>(act_out + i * VEC, y);
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) {
+        mk[e] = act_grad(y[e], act, slope);
+        g[e] *= mk[e];
+      }
+    }
     ldv<VEC>(x + i * VEC, a);
     ldv<VEC>(u + i * VEC, uu);
     ldv<VEC>(mean + c, mu);
@@ -353,7 +388,7 @@ __global__ void __launch_bounds__(256) bn_dbwd_apply_kernel(
         ox += vv[e] * r[e] * (dg - xh * m);
       }
       if (w) ogy += ww[e];
-      o1[e] = ogy;
+      o1[e] = ogy * mk[e];
       o2[e] = ox;
     }
     stv<VEC>(d_gy + i * VEC, o1);
@@ -497,21 +532,32 @@ extern "C" int vg_bn_apply(const float* x, const float* mean, const float* invst
   return VG_OK;
 }
 
+static int check_mask_act(const float* act_out, int act, const char* who) {
+  if (act_out && act != VG_ACT_RELU && act != VG_ACT_LRELU)
+    return vg_fail(VG_ERR_INVALID, "%s: only relu / leaky relu can be fused behind the norm", who);
+  return 0;
+}
+
 extern "C" int vg_bn_bwd_reduce(const float* gy, const float* x, const float* mean, const float* invstd, int M, int C,
-                                float* sums, void* ws, size_t ws_bytes, void* stream) {
+                                float* sums, void* ws, size_t ws_bytes, const float* act_out, int act, float slope,
+                                void* stream) {
   VG_REQUIRE(gy && x && mean && invstd && sums && M > 0 && C > 0, "vg_bn_bwd_reduce: bad arguments");
-  BnBwdF f{gy, x, mean, invstd};
-  return run_colreduce<2>("vg_bn_bwd_reduce", f, M, C, all_aligned({gy, x, mean, invstd}), sums, ws, ws_bytes,
+  if (int e = check_mask_act(act_out, act, "vg_bn_bwd_reduce")) return e;
+  BnBwdF f{gy, x, mean, invstd, act_out, act, slope};
+  return run_colreduce<2>("vg_bn_bwd_reduce", f, M, C, all_aligned({gy, x, mean, invstd, act_out}), sums, ws, ws_bytes,
                           (hipStream_t)stream);
 }
 
 extern "C" int vg_bn_bwd_apply(const float* gy, const float* x, const float* mean, const float* invstd, const float* gamma,
-                               const float* sums, float* gx, int M, int C, void* stream) {
+                               const float* sums, float* gx, int M, int C, const float* act_out, int act, float slope,
+                               void* stream) {
   VG_REQUIRE(gy && x && mean && invstd && sums && gx && M > 0 && C > 0, "vg_bn_bwd_apply: bad arguments");
-  const bool v4 = C % 4 == 0 && all_aligned({gy, x, mean, invstd, gamma, sums, gx});
+  if (int e = check_mask_act(act_out, act, "vg_bn_bwd_apply")) return e;
+  const bool v4 = C % 4 == 0 && all_aligned({gy, x, mean, invstd, gamma, sums, gx, act_out});
   const size_t total = (size_t)M * C;
   const float inv_n = 1.0f / (float)M;
-  VG_LAUNCH_VEC(bn_bwd_apply_kernel, v4, total, (hipStream_t)stream, gy, x, mean, invstd, gamma, sums, gx, nvec__, C, inv_n);
+  VG_LAUNCH_VEC(bn_bwd_apply_kernel, v4, total, (hipStream_t)stream, gy, x, mean, invstd, gamma, sums, gx, nvec__, C, inv_n,
+                act_out, act, slope);
   VG_CHECK_LAUNCH("vg_bn_bwd_apply");
   return VG_OK;
 }
@@ -527,22 +573,27 @@ extern "C" int vg_bn_bwd_eval(const float* gy, const float* invstd, const float*
 }
 
 extern "C" int vg_bn_dbwd_reduce(const float* gy, const float* x, const float* u, const float* mean, const float* invstd,
-                                 int M, int C, float* sums5, void* ws, size_t ws_bytes, void* stream) {
+                                 int M, int C, float* sums5, void* ws, size_t ws_bytes, const float* act_out, int act,
+                                 float slope, void* stream) {
   VG_REQUIRE(gy && x && u && mean && invstd && sums5 && M > 0 && C > 0, "vg_bn_dbwd_reduce: bad arguments");
-  BnDbwdF f{gy, x, u, mean, invstd};
-  return run_colreduce<5>("vg_bn_dbwd_reduce", f, M, C, all_aligned({gy, x, u, mean, invstd}), sums5, ws, ws_bytes,
+  if (int e = check_mask_act(act_out, act, "vg_bn_dbwd_reduce")) return e;
+  BnDbwdF f{gy, x, u, mean, invstd, act_out, act, slope};
+  return run_colreduce<5>("vg_bn_dbwd_reduce", f, M, C, all_aligned({gy, x, u, mean, invstd, act_out}), sums5, ws, ws_bytes,
                           (hipStream_t)stream);
 }
 
 extern "C" int vg_bn_dbwd_apply(const float* gy, const float* x, const float* u, const float* v, const float* w,
                                 const float* mean, const float* invstd, const float* gamma, const float* sums5, float* d_gy,
-                                float* d_x, float* d_gamma, int M, int C, void* stream) {
+                                float* d_x, float* d_gamma, int M, int C, const float* act_out, int act, float slope,
+                                void* stream) {
   VG_REQUIRE(gy && x && u && mean && invstd && sums5 && d_gy && d_x && M > 0 && C > 0, "vg_bn_dbwd_apply: bad arguments");
-  const bool v4 = C % 4 == 0 && all_aligned({gy, x, u, v, w, mean, invstd, gamma, sums5, d_gy, d_x});
+  if (int e = check_mask_act(act_out, act, "vg_bn_dbwd_apply")) return e;
+  const bool v4 = C % 4 == 0 && all_aligned({gy, x, u, v, w, mean, invstd, gamma, sums5, d_gy, d_x, act_out});
   const size_t total = (size_t)M * C;
   const float inv_n = 1.0f / (float)M;
   hipStream_t st = (hipStream_t)stream;
-  VG_LAUNCH_VEC(bn_dbwd_apply_kernel, v4, total, st, gy, x, u, v, w, mean, invstd, gamma, sums5, d_gy, d_x, nvec__, C, inv_n);
+  VG_LAUNCH_VEC(bn_dbwd_apply_kernel, v4, total, st, gy, x, u, v, w, mean, invstd, gamma, sums5, d_gy, d_x, nvec__, C, inv_n,
+                act_out, act, slope);
   VG_CHECK_LAUNCH("vg_bn_dbwd_apply");
   if (d_gamma) {
     hipLaunchKernelGGL(bn_dbwd_gamma_kernel, dim3((C + 255) / 256), dim3(256), 0, st, invstd, sums5, d_gamma, C, (float)M);

@@ -52,6 +52,8 @@ SIGNATURES = {
     "vg_conv2d_dgrad": (c_int, [_G, _P, _P, _P, _P, _P]),
     "vg_conv2d_wgrad_workspace_bytes": (c_size_t, [_G]),
     "vg_conv2d_wgrad": (c_int, [_G, _P, _P, _P, _P, c_size_t, _P]),
+    "vg_conv2d_wgrad_partial": (c_int, [_G, _P, _P, _P, _P, c_size_t, _P]),
+    "vg_conv2d_wgrad_reduce": (c_int, [_G, _P, _P, _P]),
     "vg_conv2d_variant": (c_int, [c_int, _G, ctypes.c_char_p, c_size_t]),
     "vg_nchw_to_nhwc": (c_int, [_P, _P, c_int, c_int, c_int, _P]),
     "vg_nhwc_to_nchw": (c_int, [_P, _P, c_int, c_int, c_int, _P]),
@@ -68,11 +70,12 @@ SIGNATURES = {
     "vg_bn_stats": (c_int, [_P, c_int, c_int, c_float, c_float, _P, _P, _P, _P, _P, c_size_t, _P]),
     "vg_bn_invstd_from_var": (c_int, [_P, _P, c_int, c_float, _P]),
     "vg_bn_apply": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_float, _P]),
-    "vg_bn_bwd_reduce": (c_int, [_P, _P, _P, _P, c_int, c_int, _P, _P, c_size_t, _P]),
-    "vg_bn_bwd_apply": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, c_int, _P]),
+    "vg_bn_bwd_reduce": (c_int, [_P, _P, _P, _P, c_int, c_int, _P, _P, c_size_t, _P, c_int, c_float, _P]),
+    "vg_bn_bwd_apply": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, c_int, _P, c_int, c_float, _P]),
     "vg_bn_bwd_eval": (c_int, [_P, _P, _P, _P, c_int, c_int, _P]),
-    "vg_bn_dbwd_reduce": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, _P, _P, c_size_t, _P]),
-    "vg_bn_dbwd_apply": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, _P]),
+    "vg_bn_dbwd_reduce": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, _P, _P, c_size_t, _P, c_int, c_float, _P]),
+    "vg_bn_dbwd_apply": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, _P, c_int, c_float,
+                                 _P]),
     "vg_act_fwd": (c_int, [_P, _P, c_size_t, c_int, c_float, _P]),
     "vg_act_bwd": (c_int, [_P, _P, _P, c_size_t, c_int, c_float, _P]),
     "vg_act_dbwd_ref": (c_int, [_P, _P, _P, _P, c_size_t, c_int, _P]),

@@ -36,7 +36,7 @@ class HipLinear(nn.Linear):
 
 
 class _HipBatchNorm:
-    def _hip_forward(self, x):
+    def _hip_forward(self, x, act=_hip.ACT_NONE, slope=0.0):
         # same bookkeeping as torch.nn.modules.batchnorm._BatchNorm.forward
         if self.momentum is None:
             factor = 0.0
@@ -49,21 +49,21 @@ class _HipBatchNorm:
         use_batch_stats = self.training or (self.running_mean is None and self.running_var is None)
         rm = self.running_mean if (not self.training or self.track_running_stats) else None
         rv = self.running_var if (not self.training or self.track_running_stats) else None
-        return ops.batch_norm(x, self.weight, self.bias, rm, rv, use_batch_stats, factor, self.eps)
+        return ops.batch_norm(x, self.weight, self.bias, rm, rv, use_batch_stats, factor, self.eps, act, slope)
 
 
 class HipBatchNorm2d(nn.BatchNorm2d, _HipBatchNorm):
-    def forward(self, x):
+    def forward(self, x, act=_hip.ACT_NONE, slope=0.0):
         if x.dim() != 4:
             raise ValueError("expected 4D input (got {}D input)".format(x.dim()))
-        return self._hip_forward(x)
+        return self._hip_forward(x, act, slope)
 
 
 class HipBatchNorm1d(nn.BatchNorm1d, _HipBatchNorm):
-    def forward(self, x):
+    def forward(self, x, act=_hip.ACT_NONE, slope=0.0):
         if x.dim() != 2:
             raise NotImplementedError("BatchNorm1d on %d-d input is not supported by the HIP engine" % x.dim())
-        return self._hip_forward(x)
+        return self._hip_forward(x, act, slope)
 
 
 class HipReLU(nn.ReLU):
@@ -93,7 +93,43 @@ class HipFlatten(nn.Flatten):
         return ops.flatten(x)
 
 
+def _has_hooks(m):
+    return bool(m._forward_hooks or m._forward_pre_hooks or m._backward_hooks or m._backward_pre_hooks)
+
+
+def _fused_act(norm, act):
+    """(code, slope) when `act` directly behind `norm` can run inside the norm's kernels, else None."""
+    if not isinstance(norm, (HipBatchNorm2d, HipBatchNorm1d)) or _has_hooks(norm) or _has_hooks(act):
+        return None
+    if type(act) is HipReLU:
+        return _hip.ACT_RELU, 0.0
+    if type(act) is HipLeakyReLU:
+        return _hip.ACT_LRELU, act.negative_slope
+    return None
+
+
+class HipSequential(nn.Sequential):
+    """nn.Sequential that runs a BatchNorm followed by ReLU / LeakyReLU as one fused operator: the normalised
+    pre-activation tensor is never written, and the backward kernels apply the slope mask on the fly. The pairing
+    is decided per call from the children actually present, so edits to the container keep working."""
+
+    def forward(self, x):
+        mods = list(self._modules.values())
+        i, n = 0, len(mods)
+        while i < n:
+            m = mods[i]
+            fused = _fused_act(m, mods[i + 1]) if i + 1 < n else None
+            if fused is not None:
+                x = m(x, fused[0], fused[1])
+                i += 2
+            else:
+                x = m(x)
+                i += 1
+        return x
+
+
 _SWAP = {
+    nn.Sequential: HipSequential,
     nn.Conv2d: HipConv2d,
     nn.ConvTranspose2d: HipConvTranspose2d,
     nn.Linear: HipLinear,

@@ -205,9 +205,11 @@ def raw_conv_wgrad(g, gy, x, w_shape):
         raise _hip.HipError("weight gradient shape %s does not match the geometry" % (tuple(w_shape),))
     nbytes = _hip.load().vg_conv2d_wgrad_workspace_bytes(ctypes.byref(g.c))
     ws = workspace(nbytes, x.device) if nbytes else None
-    _launch_conv(2, g, lambda: call("vg_conv2d_wgrad", ctypes.byref(g.c), _ptr(gy), _ptr(x), _ptr(gw),
-                                    ctypes.c_void_p(ws.data_ptr()) if ws is not None else None, c_size_t(nbytes),
-                                    _stream()))
+    wsp = ctypes.c_void_p(ws.data_ptr()) if ws is not None else None
+    _launch_conv(2, g, lambda: call("vg_conv2d_wgrad_partial", ctypes.byref(g.c), _ptr(gy), _ptr(x), _ptr(gw), wsp,
+                                    c_size_t(nbytes), _stream()))
+    if nbytes:
+        call("vg_conv2d_wgrad_reduce", ctypes.byref(g.c), _ptr(gw), wsp, _stream())
     return gw
 
 
@@ -355,9 +357,19 @@ def _bn_ws(m, c, device):
     return workspace(nbytes, device), nbytes
 
 
+def _act_args(y, act, slope):
+    """(act_out, act, slope) kernel arguments of a norm with a fused activation; no activation = null mask."""
+    if act == _hip.ACT_NONE:
+        return None, _hip.ACT_NONE, c_float(0.0)
+    return _ptr(y), act, c_float(slope)
+
+
 class BatchNormTrainFn(Function):
+    """Training-mode batch norm, optionally with a ReLU / LeakyReLU applied in the same pass (`act`). With a fused
+    activation the output doubles as the slope mask of the backward pass, so no pre-activation tensor exists."""
+
     @staticmethod
-    def forward(ctx, x, gamma, beta, running_mean, running_var, momentum, eps):
+    def forward(ctx, x, gamma, beta, running_mean, running_var, momentum, eps, act, slope):
         x_in = x
         x = to_nhwc(x)
         m, c = _rows_cols(x)
@@ -368,44 +380,53 @@ class BatchNormTrainFn(Function):
              _ptr(running_mean), _ptr(running_var), ctypes.c_void_p(ws.data_ptr()), c_size_t(nbytes), _stream())
         y = torch.empty_like(x)
         call("vg_bn_apply", _ptr(x), _ptr(mean), _ptr(invstd), _ptr(gamma), _ptr(beta), _ptr(y), m, c,
-             _hip.ACT_NONE, c_float(0.0), _stream())
-        ctx.save_for_backward(x_in, gamma, mean, invstd)
+             act, c_float(slope), _stream())
+        ctx.act, ctx.slope = act, slope
+        if act == _hip.ACT_NONE:
+            ctx.save_for_backward(x_in, gamma, mean, invstd)
+        else:
+            ctx.save_for_backward(x_in, gamma, mean, invstd, y)
         ctx.has_affine = (gamma is not None, beta is not None)
         return y
 
     @staticmethod
     def backward(ctx, gy):
-        x, gamma, mean, invstd = ctx.saved_tensors
-        gx, ggamma, gbeta = BatchNormBwdFn.apply(gy, x, gamma, mean, invstd)
+        x, gamma, mean, invstd = ctx.saved_tensors[:4]
+        y = ctx.saved_tensors[4] if ctx.act != _hip.ACT_NONE else None
+        gx, ggamma, gbeta = BatchNormBwdFn.apply(gy, x, gamma, mean, invstd, y, ctx.act, ctx.slope)
         return (gx, ggamma if ctx.has_affine[0] else None, gbeta if ctx.has_affine[1] else None,
-                None, None, None, None)
+                None, None, None, None, None, None)
 
 
 class BatchNormBwdFn(Function):
     """(gx, ggamma, gbeta) of training-mode batch norm as a function of (gy, x, gamma); mean/invstd are the batch
-    statistics of x (their dependence on x is part of the second derivative below)."""
+    statistics of x (their dependence on x is part of the second derivative below). `act_out` is the output of the
+    fused activation (or None): it only supplies the piecewise-constant slope mask, so it carries no gradient."""
 
     @staticmethod
-    def forward(ctx, gy, x, gamma, mean, invstd):
-        ctx.save_for_backward(gy, x, gamma, mean, invstd)
+    def forward(ctx, gy, x, gamma, mean, invstd, act_out, act, slope):
+        ctx.save_for_backward(gy, x, gamma, mean, invstd, act_out)
+        ctx.act, ctx.slope = act, slope
         gy, x = to_nhwc(gy), to_nhwc(x)
         m, c = _rows_cols(x)
+        mask = _act_args(act_out, act, slope)
         sums = torch.empty((2, c), dtype=torch.float32, device=x.device)
         ws, nbytes = _bn_ws(m, c, x.device)
         call("vg_bn_bwd_reduce", _ptr(gy), _ptr(x), _ptr(mean), _ptr(invstd), m, c, _ptr(sums),
-             ctypes.c_void_p(ws.data_ptr()), c_size_t(nbytes), _stream())
+             ctypes.c_void_p(ws.data_ptr()), c_size_t(nbytes), *mask, _stream())
         gx = torch.empty_like(x)
         call("vg_bn_bwd_apply", _ptr(gy), _ptr(x), _ptr(mean), _ptr(invstd), _ptr(gamma), _ptr(sums), _ptr(gx), m, c,
-             _stream())
+             *mask, _stream())
         ctx.set_materialize_grads(False)
         return gx, sums[1], sums[0]
 
     @staticmethod
     @once_differentiable
     def backward(ctx, u, v, w):
-        gy, x, gamma, mean, invstd = ctx.saved_tensors
+        gy, x, gamma, mean, invstd, act_out = ctx.saved_tensors
         gy, x = to_nhwc(gy), to_nhwc(x)
         m, c = _rows_cols(x)
+        mask = _act_args(act_out, ctx.act, ctx.slope)
         if u is None:
             u = torch.empty_like(x)
             call("vg_fill", _ptr(u), c_float(0.0), c_size_t(u.numel()), _stream())
@@ -415,35 +436,40 @@ class BatchNormBwdFn(Function):
         sums5 = torch.empty((5, c), dtype=torch.float32, device=x.device)
         ws, nbytes = _bn_ws(m, c, x.device)
         call("vg_bn_dbwd_reduce", _ptr(gy), _ptr(x), _ptr(u), _ptr(mean), _ptr(invstd), m, c, _ptr(sums5),
-             ctypes.c_void_p(ws.data_ptr()), c_size_t(nbytes), _stream())
+             ctypes.c_void_p(ws.data_ptr()), c_size_t(nbytes), *mask, _stream())
         d_gy = torch.empty_like(x)
         d_x = torch.empty_like(x)
         d_gamma = torch.empty(c, dtype=torch.float32, device=x.device) if gamma is not None else None
         call("vg_bn_dbwd_apply", _ptr(gy), _ptr(x), _ptr(u), _ptr(v), _ptr(w), _ptr(mean), _ptr(invstd), _ptr(gamma),
-             _ptr(sums5), _ptr(d_gy), _ptr(d_x), _ptr(d_gamma), m, c, _stream())
-        return d_gy, d_x, d_gamma, None, None
+             _ptr(sums5), _ptr(d_gy), _ptr(d_x), _ptr(d_gamma), m, c, *mask, _stream())
+        return d_gy, d_x, d_gamma, None, None, None, None, None
 
 
 class BatchNormEvalFn(Function):
     @staticmethod
-    def forward(ctx, x, gamma, beta, running_mean, running_var, eps):
+    def forward(ctx, x, gamma, beta, running_mean, running_var, eps, act, slope):
         x = to_nhwc(x)
         m, c = _rows_cols(x)
         invstd = torch.empty(c, dtype=torch.float32, device=x.device)
         call("vg_bn_invstd_from_var", _ptr(running_var), _ptr(invstd), c, c_float(eps), _stream())
         y = torch.empty_like(x)
         call("vg_bn_apply", _ptr(x), _ptr(running_mean), _ptr(invstd), _ptr(gamma), _ptr(beta), _ptr(y), m, c,
-             _hip.ACT_NONE, c_float(0.0), _stream())
-        ctx.save_for_backward(x, gamma, running_mean, invstd)
+             act, c_float(slope), _stream())
+        ctx.act, ctx.slope = act, slope
+        ctx.save_for_backward(x, gamma, running_mean, invstd, y if act != _hip.ACT_NONE else None)
         ctx.has_affine = (gamma is not None, beta is not None)
         return y
 
     @staticmethod
     @once_differentiable
     def backward(ctx, gy):
-        x, gamma, mean, invstd = ctx.saved_tensors
+        x, gamma, mean, invstd, y = ctx.saved_tensors
         gy = to_nhwc(gy)
         m, c = _rows_cols(x)
+        if y is not None:  # undo the fused activation first: g = gy * act'(y)
+            g = torch.empty_like(x)
+            call("vg_act_bwd", _ptr(gy), _ptr(y), _ptr(g), c_size_t(x.numel()), ctx.act, c_float(ctx.slope), _stream())
+            gy = g
         gx = torch.empty_like(x)
         call("vg_bn_bwd_eval", _ptr(gy), _ptr(invstd), _ptr(gamma), _ptr(gx), m, c, _stream())
         ggamma = gbeta = None
@@ -451,16 +477,19 @@ class BatchNormEvalFn(Function):
             sums = torch.empty((2, c), dtype=torch.float32, device=x.device)
             ws, nbytes = _bn_ws(m, c, x.device)
             call("vg_bn_bwd_reduce", _ptr(gy), _ptr(x), _ptr(mean), _ptr(invstd), m, c, _ptr(sums),
-                 ctypes.c_void_p(ws.data_ptr()), c_size_t(nbytes), _stream())
+                 ctypes.c_void_p(ws.data_ptr()), c_size_t(nbytes), None, _hip.ACT_NONE, c_float(0.0), _stream())
             ggamma = sums[1] if ctx.has_affine[0] else None
             gbeta = sums[0] if ctx.has_affine[1] else None
-        return gx, ggamma, gbeta, None, None, None
+        return gx, ggamma, gbeta, None, None, None, None, None
 
 
-def batch_norm(x, gamma, beta, running_mean, running_var, training, momentum, eps):
+def batch_norm(x, gamma, beta, running_mean, running_var, training, momentum, eps, act=_hip.ACT_NONE, slope=0.0):
+    """Batch norm with an optional fused ReLU / LeakyReLU (act, slope) behind it."""
+    if act not in (_hip.ACT_NONE, _hip.ACT_RELU, _hip.ACT_LRELU):
+        raise ValueError("only relu / leaky relu can be fused behind a batch norm")
     if training:
-        return BatchNormTrainFn.apply(x, gamma, beta, running_mean, running_var, momentum, eps)
-    return BatchNormEvalFn.apply(x, gamma, beta, running_mean, running_var, eps)
+        return BatchNormTrainFn.apply(x, gamma, beta, running_mean, running_var, momentum, eps, act, float(slope))
+    return BatchNormEvalFn.apply(x, gamma, beta, running_mean, running_var, eps, act, float(slope))
 
 
 # ----------------------------------------------------------------------------------------------------------------

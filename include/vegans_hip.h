@@ -72,6 +72,11 @@ int vg_conv2d_dgrad(const vg_conv_geom* g, const float* gy, const float* w, cons
 size_t vg_conv2d_wgrad_workspace_bytes(const vg_conv_geom* g);
 int vg_conv2d_wgrad(const vg_conv_geom* g, const float* gy, const float* x, float* gw,
                     void* workspace, size_t workspace_bytes, void* stream);
+/* The two phases of vg_conv2d_wgrad as separate calls (contraction into split-K slabs, then the ordered slab sum), so
+ * that a caller can time or overlap them individually; same arguments, same results. */
+int vg_conv2d_wgrad_partial(const vg_conv_geom* g, const float* gy, const float* x, float* gw,
+                            void* workspace, size_t workspace_bytes, void* stream);
+int vg_conv2d_wgrad_reduce(const vg_conv_geom* g, float* gw, const void* workspace, void* stream);
 
 /* Name of the kernel template instance the call for (mode, geometry) dispatches to (mode 0 fwd, 1 dgrad, 2 wgrad;
  * 16-byte aligned tensors assumed), as a kernel trace prints it.  No counterpart in the reference: it exists so a
@@ -123,10 +128,14 @@ int vg_bn_apply(const float* x, const float* mean, const float* invstd, const fl
                 const float* beta, float* y, int M, int C, int act, float slope, void* stream);
 /* training-mode backward: sums[0:C] = sum gy, sums[C:2C] = sum gy*xhat (=> gbeta, ggamma), then
  * gx = gamma*invstd*(gy - mean(gy) - xhat*mean(gy*xhat)) */
+/* When a ReLU / LeakyReLU is fused behind the norm (vg_bn_apply with act), pass the fused OUTPUT as act_out: the
+ * incoming gradient is then multiplied by the activation's slope mask on the fly (act_out null = no activation). */
 int vg_bn_bwd_reduce(const float* gy, const float* x, const float* mean, const float* invstd, int M, int C,
-                     float* sums, void* workspace, size_t workspace_bytes, void* stream);
+                     float* sums, void* workspace, size_t workspace_bytes, const float* act_out, int act, float slope,
+                     void* stream);
 int vg_bn_bwd_apply(const float* gy, const float* x, const float* mean, const float* invstd,
-                    const float* gamma, const float* sums, float* gx, int M, int C, void* stream);
+                    const float* gamma, const float* sums, float* gx, int M, int C, const float* act_out, int act,
+                    float slope, void* stream);
 /* eval-mode backward: gx = gy * gamma * invstd */
 int vg_bn_bwd_eval(const float* gy, const float* invstd, const float* gamma, float* gx, int M, int C,
                    void* stream);
@@ -135,10 +144,12 @@ int vg_bn_bwd_eval(const float* gy, const float* invstd, const float* gamma, flo
  * sums5[0:5C] = sum gy, sum gy*xhat, sum u, sum u*xhat, sum u*gy.
  * Outputs: d_gy [M][C], d_x [M][C], d_gamma [C]. */
 int vg_bn_dbwd_reduce(const float* gy, const float* x, const float* u, const float* mean, const float* invstd,
-                      int M, int C, float* sums5, void* workspace, size_t workspace_bytes, void* stream);
+                      int M, int C, float* sums5, void* workspace, size_t workspace_bytes, const float* act_out, int act,
+                      float slope, void* stream);
 int vg_bn_dbwd_apply(const float* gy, const float* x, const float* u, const float* v, const float* w,
                      const float* mean, const float* invstd, const float* gamma, const float* sums5,
-                     float* d_gy, float* d_x, float* d_gamma, int M, int C, void* stream);
+                     float* d_gy, float* d_x, float* d_gamma, int M, int C, const float* act_out, int act, float slope,
+                     void* stream);
 
 int vg_act_fwd(const float* x, float* y, size_t n, int act, float slope, void* stream);
 /* gx = gy * act'(.) ; `ref` is the forward INPUT for RELU/LRELU and the forward OUTPUT for TANH/SIGMOID */

@@ -136,6 +136,48 @@ def test_batch_norm_train_and_running_stats(gpu, shape):
     _close(bd.grad, br.grad, what="bn dbeta")
 
 
+@pytest.mark.parametrize("act", ["relu", "lrelu"])
+@pytest.mark.parametrize("training", [True, False])
+def test_batch_norm_with_fused_activation(gpu, act, training):
+    """BatchNorm + ReLU/LeakyReLU as one operator, and the HipSequential container that pairs them up."""
+    from torch import nn
+    from vegans.engine import modules
+    g = torch.Generator().manual_seed(17)
+    x = torch.randn(6, 12, 5, 5, generator=g) * 1.5 + 0.3
+    gy = torch.randn(6, 12, 5, 5, generator=g)
+
+    def make():
+        torch.manual_seed(5)
+        bn = nn.BatchNorm2d(12)
+        with torch.no_grad():
+            bn.weight.uniform_(0.5, 1.5)
+            bn.bias.normal_()
+            bn.running_mean.normal_()
+            bn.running_var.uniform_(0.5, 1.5)
+        return nn.Sequential(bn, nn.ReLU() if act == "relu" else nn.LeakyReLU(0.2), nn.Identity())
+
+    ref, dut = make().train(training), modules.bind(make()).to(gpu).train(training)
+    assert type(dut) is modules.HipSequential
+    xr = x.clone().requires_grad_(True)
+    yr = ref(xr)
+    yr.backward(gy)
+    xd = x.to(gpu).requires_grad_(True)
+    y = dut(xd)
+    assert "BatchNorm" in type(y.grad_fn).__name__, type(y.grad_fn).__name__   # one operator, no separate activation
+    y.backward(gy.to(gpu))
+    _close(y, yr, what="fused bn+act fwd")
+    _close(xd.grad, xr.grad, what="fused bn+act dx")
+    _close(dut[0].weight.grad, ref[0].weight.grad, what="fused bn+act dgamma")
+    _close(dut[0].bias.grad, ref[0].bias.grad, what="fused bn+act dbeta")
+    _close(dut[0].running_mean, ref[0].running_mean, what="running mean")
+    _close(dut[0].running_var, ref[0].running_var, what="running var")
+    # a hook on the activation must still see a separate call
+    dut[1].register_forward_hook(lambda m, i, o: None)
+    y2 = dut(x.to(gpu))
+    _close(y2, ref(x), what="unfused because of the hook")
+    assert modules._fused_act(dut[0], dut[1]) is None
+
+
 def test_batch_norm_eval(gpu):
     from vegans.engine import ops
     g = torch.Generator().manual_seed(3)
@@ -245,8 +287,10 @@ def test_concat_and_layout_bit_exact(gpu):
     assert torch.equal(ops.to_nhwc(t).cpu(), t.cpu())  # logical values unchanged by a layout change
 
 
-def test_gradient_penalty_with_bn_critic_double_backward(gpu):
-    """Second-order path: conv -> BN -> leaky relu -> conv -> BN -> leaky relu -> conv, penalty on d out / d in."""
+@pytest.mark.parametrize("fused", [False, True])
+def test_gradient_penalty_with_bn_critic_double_backward(gpu, fused):
+    """Second-order path: conv -> BN -> leaky relu -> conv -> BN -> leaky relu -> conv, penalty on d out / d in;
+    once with separate norm and activation operators, once with the activation fused into the norm's kernels."""
     from vegans import _hip
     from vegans.engine import ops
     g = torch.Generator().manual_seed(21)
@@ -266,12 +310,15 @@ def test_gradient_penalty_with_bn_critic_double_backward(gpu):
         h = F.leaky_relu(F.batch_norm(h, None, None, g2, b2, True, 0.1, 1e-5), 0.2)
         return F.conv2d(h, w3, None, 1, 0).flatten(1)
 
+    def norm_act(h, gamma, beta):
+        if fused:
+            return ops.batch_norm(h, gamma, beta, None, None, True, 0.1, 1e-5, _hip.ACT_LRELU, 0.2)
+        return ops.activation(ops.batch_norm(h, gamma, beta, None, None, True, 0.1, 1e-5), _hip.ACT_LRELU, 0.2)
+
     def hip_critic(inp, p):
         w1, g1, b1, w2, g2, b2, w3 = p
-        h = ops.conv2d(inp, w1, None, (2, 2), (1, 1))
-        h = ops.activation(ops.batch_norm(h, g1, b1, None, None, True, 0.1, 1e-5), _hip.ACT_LRELU, 0.2)
-        h = ops.conv2d(h, w2, None, (2, 2), (1, 1))
-        h = ops.activation(ops.batch_norm(h, g2, b2, None, None, True, 0.1, 1e-5), _hip.ACT_LRELU, 0.2)
+        h = norm_act(ops.conv2d(inp, w1, None, (2, 2), (1, 1)), g1, b1)
+        h = norm_act(ops.conv2d(h, w2, None, (2, 2), (1, 1)), g2, b2)
         return ops.flatten(ops.conv2d(h, w3, None, (1, 1), (0, 0)))
 
     params = [w1, g1, b1, w2, g2, b2, w3]
