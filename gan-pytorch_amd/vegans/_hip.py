@@ -128,7 +128,8 @@ def _check(rc, name):
 
 
 def _stream():
-    return c_void_p(torch.cuda.current_stream().cuda_stream)
+    """Raw handle of torch's current HIP stream on the current device."""
+    return c_void_p(torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice()))
 
 
 def _ptr(t):
@@ -149,6 +150,14 @@ def _dense(t):
 
 
 _workspace = {}
+_workspace_frozen = False
+
+
+def freeze_workspace(frozen):
+    """While frozen (a HIP graph is being captured) the scratch buffer must not be replaced: a buffer allocated during
+    capture would belong to that graph's memory pool and die with it."""
+    global _workspace_frozen
+    _workspace_frozen = bool(frozen)
 
 
 def workspace(nbytes, device):
@@ -156,6 +165,8 @@ def workspace(nbytes, device):
     key = device.index if device.index is not None else torch.cuda.current_device()
     buf = _workspace.get(key)
     if buf is None or buf.numel() < nbytes:
+        if _workspace_frozen:
+            raise HipError("scratch buffer would have to grow to %d bytes during graph capture" % nbytes)
         nbytes = max(int(nbytes), 1 << 20)
         buf = torch.empty(nbytes, dtype=torch.uint8, device=device)
         _workspace[key] = buf

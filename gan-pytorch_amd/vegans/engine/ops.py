@@ -118,28 +118,47 @@ def _check_shape(t, shape, what):
 # ----------------------------------------------------------------------------------------------------------------
 # raw kernels (no autograd)
 # ----------------------------------------------------------------------------------------------------------------
+_variant_names = {}
+
+
+def conv_variant(mode, g):
+    """Name of the kernel the library runs for convolution `mode` (0 fwd, 1 dgrad, 2 wgrad) on geometry g."""
+    c = g.c
+    key = (mode, c.N, c.H, c.W, c.Ci, c.Co, c.kh, c.kw, c.Ho, c.Wo, c.sh, c.sw, c.ph, c.pw)
+    name = _variant_names.get(key)
+    if name is None:
+        buf = ctypes.create_string_buffer(128)
+        call("vg_conv2d_variant", mode, ctypes.byref(c), buf, c_size_t(128))
+        name = _variant_names[key] = buf.value.decode()
+    return name
+
+
 class ConvTimer:
     """Optional event timing of the convolution kernels (installed by the benchmark): start/stop events are
-    recorded on the stream the kernel is launched on; durations are read after the timed region."""
+    recorded on the stream the kernel is launched on; durations are read after the timed region. With `only` set,
+    just the launches of that kernel variant are bracketed (two event records per launch perturb the stream, so the
+    benchmark's timed region instruments one kernel, not all of them)."""
 
-    def __init__(self):
-        self.records = []   # (mode, geometry, start_event, stop_event)
+    def __init__(self, only=None):
+        self.only = only
+        self.records = []   # (variant, geometry, start_event, stop_event, mode)
 
     def launch(self, mode, g, fn):
+        name = conv_variant(mode, g)
+        if self.only is not None and name != self.only:
+            fn()
+            return
         start = torch.cuda.Event(enable_timing=True)
         stop = torch.cuda.Event(enable_timing=True)
         start.record()
         fn()
         stop.record()
-        self.records.append((mode, g, start, stop))
+        self.records.append((name, g, start, stop, mode))
 
     def summary(self):
         """{kernel variant: (launches, total_ms, total_algorithmic_flops)}; call after torch.cuda.synchronize()."""
         out = {}
-        buf = ctypes.create_string_buffer(128)
-        for mode, g, start, stop in self.records:
-            call("vg_conv2d_variant", mode, ctypes.byref(g.c), buf, c_size_t(128))
-            key = buf.value.decode()
+        for key, g, start, stop, _ in self.records:
             flops = 2.0 * g.N * g.Ho * g.Wo * g.Co * g.kh * g.kw * g.Ci
             n, ms, fl = out.get(key, (0, 0.0, 0.0))
             out[key] = (n + 1, ms + start.elapsed_time(stop), fl + flops)

@@ -12,6 +12,7 @@ from ctypes import byref, c_float, c_size_t
 import torch
 
 from .. import _hip
+from . import graph
 from .._hip import AdamCfg, RmspropCfg, SgdCfg, _ptr, _stream, call
 
 _NO_CLAMP = (1.0, -1.0)  # lo > hi disables the clamp inside the kernels
@@ -75,7 +76,7 @@ def _rmsprop(opt, grad_scale, lo, hi):
                     state["momentum_buffer"] = _zeros_like(p)
                 if group["centered"]:
                     state["grad_avg"] = _zeros_like(p)
-            state["step"] += 1
+            graph.host_effect(lambda st=state: st["step"].add_(1))
             cfg = RmspropCfg(_as_float(group["lr"]), group["alpha"], group["eps"], group["weight_decay"],
                              group["momentum"], 1 if group["centered"] else 0, sign * grad_scale, lo, hi)
             call("vg_rmsprop_step", _ptr(p.data), _ptr(_grad_mem(p)), _ptr(state["square_avg"]),

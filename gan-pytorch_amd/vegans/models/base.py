@@ -24,7 +24,7 @@ from datetime import datetime
 import numpy as np
 import torch
 
-from ..engine import ops, optim as hip_optim, parallel
+from ..engine import graph, ops, optim as hip_optim, parallel
 from ..utils import utils
 
 
@@ -270,7 +270,11 @@ class AbstractGenerativeModel(ABC):
 
     def train_on_batch(self, X, Z):
         """The body of the hot loop (AbstractGenerativeModel.py:321-327) for one batch that already lives on the
-        GPU: every network in `neural_nets` order, `steps[name]` sub-steps each, all on the same X and Z."""
+        GPU: every network in `neural_nets` order, `steps[name]` sub-steps each, all on the same X and Z.  After a
+        couple of eager calls the body is replayed from a captured HIP graph (engine/graph.py)."""
+        graph.run_step(self, self._train_on_batch_body, (X, Z))
+
+    def _train_on_batch_body(self, X, Z):
         for name in self.neural_nets:
             for _ in range(self.steps[name]):
                 self._losses = {}
@@ -605,6 +609,9 @@ class AbstractConditionalGenerativeModel(AbstractGenerativeModel):
 
     def train_on_batch(self, X, y, Z):
         """Conditional twin of the hot-loop body (AbstractConditionalGenerativeModel.py:135-141)."""
+        graph.run_step(self, self._train_on_batch_body, (X, y, Z))
+
+    def _train_on_batch_body(self, X, y, Z):
         for name in self.neural_nets:
             for _ in range(self.steps[name]):
                 self._losses = {}

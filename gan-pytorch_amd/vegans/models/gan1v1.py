@@ -14,7 +14,7 @@ kernels as constants; no target tensors are materialised and nothing is read bac
 import numpy as np
 import torch
 
-from ..engine import ops
+from ..engine import graph, ops
 from ..utils import utils
 from ..utils.networks import Adversariat, Generator
 from .base import AbstractConditionalGenerativeModel, AbstractGenerativeModel, resolve_device
@@ -132,11 +132,12 @@ class _PenaltyMixin:
         dp = getattr(self, "_dp", None)
         if dp is not None and dp.world > 1:
             # every rank draws the alphas of the whole batch (same numpy seed) and keeps its rows
-            alpha = dp.shard(np.random.random((dp.global_rows, 1, 1, 1)))
+            def draw():
+                return dp.shard(np.random.random((dp.global_rows, 1, 1, 1)))
         else:
-            alpha = np.random.random((n_local, 1, 1, 1))
-        # pinned staging + asynchronous copy: a pageable copy would block the host until the stream drains
-        return torch.from_numpy(alpha.astype(np.float32)).pin_memory().to(self.device, non_blocking=True)
+            def draw():
+                return np.random.random((n_local, 1, 1, 1))
+        return graph.host_input((n_local, 1, 1, 1), draw, self.device)
 
     def _gradient_penalty(self, real_images, fake_images):
         alpha = self._draw_alpha(real_images.size(0))

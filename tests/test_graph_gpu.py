@@ -1,0 +1,160 @@
+"""The captured training step (engine/graph.py) against the same step run kernel by kernel.
+
+A replayed HIP graph launches the very kernels the eager path launches on the same data, and every kernel of the
+library is deterministic (no atomics), so for the clipped Wasserstein GAN everything must agree BIT FOR BIT:
+parameters, BatchNorm buffers, optimizer state, published losses and gradients.
+
+With the gradient penalty a critic weight receives four gradient contributions (fake, real and two from the
+double-backward pass) which torch's autograd engine adds in the order its scheduler reaches them; that order depends
+on sequence counters of two threads and changes between iterations and between two eager runs of one process
+(measured: eager vs eager differs by 1 ulp of the largest gradient element from the fourth iteration on), while a
+graph replays the order of the iteration it captured.  There the comparison is to 1e-5 of each tensor's largest
+magnitude, plus an exact check that the host random stream (numpy alphas) advanced identically.
+"""
+import copy
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _model(algo, steps=None, seed=4, **extra):
+    import bench_configs as cfg
+    import vegans.GAN as gan
+    torch.manual_seed(seed)
+    np.random.seed(seed)
+    G = cfg.seeded_init(cfg.dcgan_generator(nz=16, ngf=8, nc=3, size=16), 1, 0.08)
+    D = cfg.seeded_init(cfg.dcgan_critic(ndf=8, nc=3, size=16), 2, 0.08)
+    okw = {"Generator": {"lr": 1e-3}, "Adversariat": {"lr": 5e-4}}
+    m = getattr(gan, algo)(G, D, x_dim=(3, 16, 16), z_dim=(16, 1, 1), optim_kwargs=okw, folder=None,
+                           fixed_noise_size=4, **extra)
+    m._create_steps(copy.deepcopy(steps))
+    m.train()
+    return m
+
+
+def _run(m, batches, latents, use_graph):
+    from vegans.engine import graph
+    m.use_step_graph = use_graph
+    np.random.seed(77)
+    losses = []
+    for X, Z in zip(batches, latents):
+        m.train_on_batch(X, Z)
+        losses.append({k: v.detach().clone() for k, v in m._losses.items()})
+    torch.cuda.synchronize()
+    entries = list(graph._graphs.get(m, {}).values())
+    return losses, np.random.random(), entries
+
+
+def _state(m):
+    out = {}
+    for name, net in m.neural_nets.items():
+        for k, v in net.state_dict().items():
+            out[name + "." + k] = v.detach().clone()
+        for i, p in enumerate(net.parameters()):
+            for k, v in m.optimizers[name].state[p].items():
+                out["%s.opt%d.%s" % (name, i, k)] = v.detach().clone() if isinstance(v, torch.Tensor) else v
+            out["%s.grad%d" % (name, i)] = None if p.grad is None else p.grad.detach().clone()
+    return out
+
+
+def _same(a, b, exact, what):
+    if exact:
+        assert torch.equal(a, b), what
+    else:
+        scale = max(float(b.abs().max()), 1e-3)
+        err = float((a.double() - b.double()).abs().max())
+        assert err <= 1e-5 * scale, "%s: |diff| %.3e vs scale %.3e" % (what, err, scale)
+
+
+@pytest.mark.parametrize("algo,steps,extra,exact", [
+    ("WassersteinGAN", {"Adversariat": 3}, {"clip_val": 0.02}, True),
+    ("WassersteinGAN", None, {}, True),
+    ("WassersteinGANGP", None, {}, False),
+])
+def test_replayed_step_matches_eager(gpu, algo, steps, extra, exact):
+    import bench_configs as cfg
+    iters, B = 7, 8
+    data = cfg.synthetic_images(B * iters, (3, 16, 16), seed=8)
+    g = torch.Generator().manual_seed(12)
+    zs = [torch.randn(B, 16, 1, 1, generator=g) for _ in range(iters)]
+
+    results = []
+    for use_graph in (False, True):
+        m = _model(algo, steps, **extra)
+        batches = [m._to_device(data[i * B:(i + 1) * B]) for i in range(iters)]
+        latents = [z.to("cuda") for z in zs]
+        losses, next_draw, entries = _run(m, batches, latents, use_graph)
+        if use_graph:
+            assert len(entries) == 1 and entries[0].graph is not None and not entries[0].failed
+            assert entries[0].eager_calls == 2          # two eager calls, the rest replayed
+        else:
+            assert entries == []
+        results.append((losses, next_draw, _state(m)))
+
+    (l0, r0, s0), (l1, r1, s1) = results
+    assert r0 == r1, "host random stream advanced differently under replay"
+    for i, (a, b) in enumerate(zip(l0, l1)):
+        assert set(a) == set(b)
+        for k in a:
+            if k == "RealFakeRatio" and not exact:
+                continue                                  # a quotient of two losses, logged only
+            _same(a[k].reshape(1), b[k].reshape(1), exact, "iteration %d loss %s" % (i, k))
+    assert set(s0) == set(s1)
+    for k in s0:
+        if isinstance(s0[k], torch.Tensor):
+            _same(s0[k].float(), s1[k].float(), exact or ".opt" in k and k.endswith("step"), k)
+        else:
+            assert s0[k] == s1[k], k
+
+
+def test_graph_follows_hyperparameter_and_shape_changes(gpu):
+    """Values frozen into a graph are part of its signature: a new learning rate or batch shape takes a new graph
+    (after its own eager calls) instead of replaying stale constants."""
+    import bench_configs as cfg
+    from vegans.engine import graph
+    m = _model("WassersteinGANGP")
+    X = m._to_device(cfg.synthetic_images(8, (3, 16, 16), seed=1))
+    Z = torch.randn(8, 16, 1, 1, device="cuda")
+    for _ in range(4):
+        m.train_on_batch(X, Z)
+    assert len(graph._graphs[m]) == 1
+    m.optimizers["Generator"].param_groups[0]["lr"] = 5e-3
+    before = [p.detach().clone() for p in m.generator.parameters()]
+    for _ in range(4):
+        m.train_on_batch(X, Z)
+    assert len(graph._graphs[m]) == 2
+    # an RMSprop step moves a weight by at most lr / (sqrt(1 - alpha) + eps) = 10 lr; four steps at the new rate move
+    # further than four steps at the old rate ever could
+    moved = max(float((p.detach() - b).abs().max()) for p, b in zip(m.generator.parameters(), before))
+    assert moved > 4 * 10 * 1e-3 * 0.5, moved
+    m.train_on_batch(X[:5].contiguous(memory_format=torch.channels_last), Z[:5].contiguous())   # ragged last batch
+    assert len(graph._graphs[m]) == 3
+    m.eval()
+    assert not graph._eligible(m)                # not in training mode: never captured or replayed
+    m.train()
+    m.use_step_graph = False
+    assert not graph._eligible(m)
+    graph.reset(m)
+    assert m not in graph._graphs
+
+
+def test_fit_through_graph_matches_fit_without(gpu):
+    """The public `fit` (logging and a ragged last batch in between) gives bit-identical weights either way
+    (clipped Wasserstein GAN: see the module docstring for why the penalty variant is not bit-reproducible)."""
+    import bench_configs as cfg
+    X = cfg.synthetic_images(8 * 6 + 3, (3, 16, 16), seed=3)
+    finals = []
+    for use_graph in (False, True):
+        m = _model("WassersteinGAN", seed=9)
+        m.use_step_graph = use_graph
+        torch.manual_seed(21)        # latent draws
+        m.fit(X, epochs=2, batch_size=8, print_every=None, save_losses_every=3, enable_tensorboard=False)
+        finals.append(({k: v.clone() for k, v in m.generator.state_dict().items()},
+                       {k: v.clone() for k, v in m.adversariat.state_dict().items()}, m.get_losses()))
+    for a, b in zip(finals[0][:2], finals[1][:2]):
+        for k in a:
+            assert torch.equal(a[k], b[k]), k
+    assert finals[0][2] == finals[1][2]

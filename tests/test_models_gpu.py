@@ -41,6 +41,9 @@ def _build_model(case, nets, device="cuda"):
 
 def _inject(model, latents, alphas, record):
     """Feed recorded latent batches and alphas through the model's own draw hooks; log each sub-step's losses."""
+    # the hooks below live on the host side of every sub-step, so the iterations must run one by one (the replay of a
+    # captured step is compared bit for bit with this eager path in test_graph_gpu.py)
+    model.use_step_graph = False
     zs, al = iter(latents), iter(alphas)
     model.sample = lambda n: next(zs).to("cuda").requires_grad_(True)
     if hasattr(model, "_draw_alpha"):

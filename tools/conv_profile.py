@@ -35,7 +35,7 @@ def main():
     torch.cuda.synchronize()
     ops.conv_timer = None
     agg = {}
-    for mode, g, start, stop in timer.records:
+    for _, g, start, stop, mode in timer.records:
         key = (mode, g.N, g.H, g.W, g.Ci, g.Co, g.kh, g.sh, g.ph)
         n, ms = agg.get(key, (0, 0.0))
         agg[key] = (n + 1, ms + start.elapsed_time(stop))
