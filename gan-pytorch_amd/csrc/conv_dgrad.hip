@@ -27,6 +27,7 @@ extern "C" int vg_conv2d_dgrad(const vg_conv_geom* g, const float* gy, const flo
   // Largest parity class bounds the grid; smaller classes retire their surplus blocks at entry.
   const int Hc = (g->H + g->sh - 1) / g->sh, Wc = (g->W + g->sw - 1) / g->sw;
   p.M = g->N * Hc * Wc;
+  p.fast_div = p.M < (1 << 22) ? 1 : 0;
   p.Ktot = 0;  // per class, derived in the kernel
   const int bn = igemm_pick_bn(p.Ncols);
   p.ntiles = (p.Ncols + bn - 1) / bn;

@@ -30,6 +30,7 @@ extern "C" int vg_conv2d_fwd(const vg_conv_geom* g, const float* x, const float*
   p.N = g->N; p.H = g->H; p.W = g->W; p.Ci = g->Ci; p.Co = g->Co; p.KH = g->kh; p.KW = g->kw;
   p.Ho = g->Ho; p.Wo = g->Wo; p.sh = g->sh; p.sw = g->sw; p.ph = g->ph; p.pw = g->pw;
   p.M = g->N * g->Ho * g->Wo;
+  p.fast_div = p.M < (1 << 22) ? 1 : 0;
   p.Ncols = g->Co;
   p.Ktot = g->kh * g->kw * g->Ci;
   p.bias_mod = g->Co;
@@ -56,6 +57,7 @@ int vg_gemm_kn(const float* A, const float* B, const float* bias, int bias_mod, 
   p.N = M; p.H = 1; p.W = 1; p.Ci = K; p.Co = Ncols; p.KH = 1; p.KW = 1;
   p.Ho = 1; p.Wo = 1; p.sh = 1; p.sw = 1; p.ph = 0; p.pw = 0;
   p.M = M; p.Ncols = Ncols; p.Ktot = K; p.bias_mod = bias_mod;
+  p.fast_div = p.M < (1 << 22) ? 1 : 0;
   const int bn = igemm_pick_bn(Ncols);
   p.ntiles = (Ncols + bn - 1) / bn;
   const int bm = igemm_pick_bm(M, p.ntiles, 1, bn);

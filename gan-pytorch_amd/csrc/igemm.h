@@ -26,6 +26,10 @@ static __device__ __attribute__((aligned(16))) float vg_zero_page[4] = {0.f, 0.f
 // n / d for 0 <= n < 2^22 and small positive d, with inv = 1.0f / d: exact because (n + 0.5) / d is at least
 // 0.5 / d away from the next integer, far more than the float rounding of the product.
 __device__ __forceinline__ int vg_div_small(int n, float inv) { return (int)(((float)n + 0.5f) * inv); }
+// the same when `fast` (a kernel-uniform flag saying n stays below 2^22), else a true integer division
+__device__ __forceinline__ int vg_div_row(int n, int d, float inv, bool fast) {
+  return fast ? vg_div_small(n, inv) : n / d;
+}
 
 struct IgemmParams {
   const float* A;     // fwd: x      dgrad: gy     wgrad: gy
@@ -36,6 +40,7 @@ struct IgemmParams {
   int M, Ncols, Ktot;  // fwd/wgrad GEMM extents (dgrad derives M and Ktot per parity class)
   int mtiles, ntiles;
   int kchunk;          // wgrad: k extent per split (multiple of 32)
+  int fast_div;        // all row indices < 2^22: row -> (image, y, x) decoding may use float reciprocals
   int bias_mod;
   long long slab_stride;  // wgrad: elements per split-K slab
 };
@@ -53,7 +58,8 @@ __global__ void __launch_bounds__(256) igemm_kernel(const IgemmParams p) {
   static_assert(TM >= 1 && TN >= 1, "tile too small for the wave arrangement");
 
   // two staging buffers: tile t+1 is written while tile t is being read, one barrier per k-step
-  constexpr int BUF = (BM + BN) * LDK;
+  constexpr int A_FLOATS = A_MC ? BK * BM : BM * LDK, B_FLOATS = B_IS_MC ? BK * BN : BN * LDK;
+  constexpr int BUF = A_FLOATS + B_FLOATS;
   __shared__ __attribute__((aligned(16))) float smem[2 * BUF];
 
   const int tid = threadIdx.x;
@@ -105,6 +111,11 @@ __global__ void __launch_bounds__(256) igemm_kernel(const IgemmParams p) {
   constexpr int RA = BM / 32;  // rows per thread, [row][k] layout
   constexpr int TPRA = BM / 4, RPA = 256 / TPRA, PA = BK / RPA;  // [k][row] layout
   int a_img[A_MC ? 1 : RA], a_h[A_MC ? 1 : RA], a_w[A_MC ? 1 : RA];
+  // row index -> (image, y, x): plane = pixels per image, roww = pixels per image row, of the tensor the rows walk
+  const bool fast = p.fast_div != 0;
+  const int roww = (MODE == MODE_FWD) ? p.Wo : Wc;
+  const int plane = (MODE == MODE_FWD) ? p.Ho * p.Wo : Hc * Wc;
+  const float inv_roww = roww > 0 ? 1.0f / (float)roww : 0.f, inv_plane = plane > 0 ? 1.0f / (float)plane : 0.f;
   if constexpr (!A_MC) {
 #pragma unroll
     for (int i = 0; i < RA; ++i) {
@@ -114,16 +125,14 @@ __global__ void __launch_bounds__(256) igemm_kernel(const IgemmParams p) {
       a_h[i] = -(1 << 28);
       if (m < M) {
         if constexpr (MODE == MODE_FWD) {
-          const int hw = p.Ho * p.Wo;
-          const int n = m / hw, rem = m - n * hw;
-          const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
+          const int n = vg_div_row(m, plane, inv_plane, fast), rem = m - n * plane;
+          const int ho = vg_div_row(rem, roww, inv_roww, fast), wo = rem - ho * roww;
           a_img[i] = n * p.H * p.W;
           a_h[i] = ho * p.sh - p.ph;
           a_w[i] = wo * p.sw - p.pw;
         } else {
-          const int hw = Hc * Wc;
-          const int n = m / hw, rem = m - n * hw;
-          const int ii = rem / Wc, jj = rem - ii * Wc;
+          const int n = vg_div_row(m, plane, inv_plane, fast), rem = m - n * plane;
+          const int ii = vg_div_row(rem, roww, inv_roww, fast), jj = rem - ii * roww;
           a_img[i] = n * p.Ho * p.Wo;
           a_h[i] = ii + base_h;
           a_w[i] = jj + base_w;
@@ -380,7 +389,7 @@ __global__ void __launch_bounds__(256) igemm_kernel(const IgemmParams p) {
 
   auto store_tiles = [&](int buf) {
     float* As = smem + buf * BUF;
-    float* Bs = As + BM * LDK;
+    float* Bs = As + A_FLOATS;
     if constexpr (!A_MC) {
 #pragma unroll
       for (int i = 0; i < RA; ++i)
@@ -409,9 +418,10 @@ __global__ void __launch_bounds__(256) igemm_kernel(const IgemmParams p) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.f;
 
-  // one 8-deep slice of the current tile: fragment reads, then 4 * TM * TN MFMAs
-  auto mma_slice = [&](const float* As, const float* Bs, int s) {
-    f32x4 af[TM], bf[TN];
+  // Fragments of one 8-deep slice of a staged tile, and the 4 * TM * TN MFMAs that consume them. The two are separate
+  // so the reads of slice s+1 are in flight while the MFMAs of slice s run (two fragment register sets): a block
+  // that is alone on its CU has no other wave to hide the LDS latency behind.
+  auto load_frags = [&](const float* As, const float* Bs, int s, f32x4 (&af)[TM], f32x4 (&bf)[TN]) {
 #pragma unroll
     for (int mi = 0; mi < TM; ++mi) {
       const int row = (wm * TM + mi) * 32 + r;
@@ -432,6 +442,8 @@ __global__ void __launch_bounds__(256) igemm_kernel(const IgemmParams p) {
         for (int j = 0; j < 4; ++j) bf[ni][j] = Bs[(8 * s + 4 * h + j) * BN + col];
       }
     }
+  };
+  auto mma_frags = [&](const f32x4 (&af)[TM], const f32x4 (&bf)[TN]) {
 #pragma unroll
     for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -441,27 +453,42 @@ __global__ void __launch_bounds__(256) igemm_kernel(const IgemmParams p) {
           acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mi][j], bf[ni][j], acc[mi][ni], 0, 0, 0);
   };
 
-  // One k-step on buffer `buf`: the next tile's global loads are issued first and stay in flight under the first
-  // half of the MFMAs; they are written to the other buffer (last read one k-step ago, behind a barrier) before
-  // the second half, so the store latency hides under MFMAs too.
+  f32x4 afx[TM], bfx[TN], afy[TM], bfy[TN];
+
+  // One k-step on buffer `buf`. On entry afx/bfx hold slice 0 of that buffer and the staging registers hold tile
+  // kt+1, whose global loads were issued a whole k-step ago. Mid-step that tile is written to the other buffer (last
+  // read one k-step ago, behind a barrier) and the loads of tile kt+2 are issued into the freed registers. After the
+  // barrier the first slice of the next buffer is fetched under the MFMAs of the last slice.
   auto k_step = [&](int kt, int buf) {
-    const bool more = kt + 1 < nk;
-    if (more) load_tiles();
     const float* As = smem + buf * BUF;
-    const float* Bs = As + BM * LDK;
-    mma_slice(As, Bs, 0);
-    mma_slice(As, Bs, 1);
-    if (more) store_tiles(buf ^ 1);
-    mma_slice(As, Bs, 2);
-    mma_slice(As, Bs, 3);
+    const float* Bs = As + A_FLOATS;
+    load_frags(As, Bs, 1, afy, bfy);
+    __builtin_amdgcn_sched_barrier(0);
+    mma_frags(afx, bfx);
+    load_frags(As, Bs, 2, afx, bfx);
+    __builtin_amdgcn_sched_barrier(0);
+    mma_frags(afy, bfy);
+    if (kt + 1 < nk) store_tiles(buf ^ 1);
+    if (kt + 2 < nk) load_tiles();
+    load_frags(As, Bs, 3, afy, bfy);
+    __builtin_amdgcn_sched_barrier(0);
+    mma_frags(afx, bfx);
     __syncthreads();
+    if (kt + 1 < nk) {
+      const float* An = smem + (buf ^ 1) * BUF;
+      load_frags(An, An + A_FLOATS, 0, afx, bfx);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    mma_frags(afy, bfy);
   };
 
   if (nk > 0) {
     load_tiles();
     store_tiles(0);
+    if (nk > 1) load_tiles();
   }
   __syncthreads();
+  if (nk > 0) load_frags(smem, smem + A_FLOATS, 0, afx, bfx);
 
   int kt = 0;
   for (; kt + 1 < nk; kt += 2) {
@@ -481,9 +508,8 @@ __global__ void __launch_bounds__(256) igemm_kernel(const IgemmParams p) {
       if (row >= M) continue;
       size_t rowoff;
       if constexpr (MODE == MODE_DGRAD) {
-        const int hw = Hc * Wc;
-        const int n = row / hw, rem = row - n * hw;
-        const int ii = rem / Wc, jj = rem - ii * Wc;
+        const int n = vg_div_row(row, plane, inv_plane, fast), rem = row - n * plane;
+        const int ii = vg_div_row(rem, roww, inv_roww, fast), jj = rem - ii * roww;
         rowoff = (size_t)((n * p.H + ii * p.sh + off_h) * p.W + jj * p.sw + off_w) * p.Ncols;
       } else {
         rowoff = (size_t)row * p.Ncols;
