@@ -146,6 +146,94 @@ __global__ void __launch_bounds__(256) dgrad_thin_kernel(const float* __restrict
   }
 }
 
+// ---- dgrad, Ci <= 4, scatter form ---------------------------------------------------------------------------------
+// One thread per gy pixel: it reads its Co values straight from global memory (16-byte loads, no staging) and forms
+// all KH*KW*CI products with the weights, which are uniform over the block and arrive as scalar operands in
+// 16-dword loads ([Co][kh][kw][Ci] keeps the KH*KW*CI weights of one co contiguous). Every gy value is read once
+// and used KH*KW*CI times from a register. The per-pixel partial results go to LDS, and a second phase lets every
+// output pixel of the block's tile add up the (at most ceil(KH/sh)*ceil(KW/sw)) partials that land on it, in tap
+// order. A tile is RH x RW gy pixels; neighbouring tiles overlap by ceil(K/s)-1 rows/columns so that every output
+// pixel finds all its partials inside one tile (no atomics); a tile that spans a whole dimension needs no overlap.
+template <int CI, int TAPS>
+__global__ void __launch_bounds__(256) dgrad_scatter_kernel(const float* __restrict__ gy, const float* __restrict__ w,
+                                                            const float* __restrict__ bias, float* __restrict__ gx, int H,
+                                                            int W, int Co, int KH, int KW, int Ho, int Wo, int sh, int sw,
+                                                            int ph, int pw, int RW, int tiles_h, int tiles_w, int step_h,
+                                                            int step_w, int org_h, int org_w) {
+  constexpr int NP = TAPS * CI;
+  constexpr int LDP = NP | 1;  // odd row stride: conflict-free column writes
+  __shared__ float part[256 * LDP];
+  const int RH = 256 / RW;
+  int bid = blockIdx.x;
+  const int tw = bid % tiles_w; bid /= tiles_w;
+  const int th = bid % tiles_h;
+  const int n = bid / tiles_h;
+  const int h0 = th * step_h + org_h, w0 = tw * step_w + org_w;   // first gy row / column of the tile
+  const int ty = threadIdx.x / RW, tx = threadIdx.x - ty * RW;
+  const int ho = h0 + ty, wo = w0 + tx;
+
+  float acc[NP];
+#pragma unroll
+  for (int k = 0; k < NP; ++k) acc[k] = 0.f;
+  if ((unsigned)ho < (unsigned)Ho && (unsigned)wo < (unsigned)Wo) {
+    const float* g = gy + ((size_t)(n * Ho + ho) * Wo + wo) * Co;
+    // the next quad of channels is fetched while the current one is being used
+    f32x4 gv = *reinterpret_cast<const f32x4*>(g);
+    for (int co = 0; co < Co; co += 4) {
+      const int nx = co + 4 < Co ? co + 4 : co;
+      const f32x4 gn = *reinterpret_cast<const f32x4*>(g + nx);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float* wc = w + (size_t)(co + e) * NP;
+#pragma unroll
+        for (int k = 0; k < NP; ++k) acc[k] = fmaf(gv[e], wc[k], acc[k]);
+      }
+      gv = gn;
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < NP; ++k) part[threadIdx.x * LDP + k] = acc[k];
+  __syncthreads();
+
+  // output pixels owned by this tile: rows whose lowest contributing gy row lies in [h0, h0 + step_h) (all rows when
+  // the tile spans the dimension), likewise for columns
+  const int hi_lo = tiles_h == 1 ? 0 : sh * (h0 - 1) - ph + KH, OH = tiles_h == 1 ? H : sh * step_h;
+  const int wi_lo = tiles_w == 1 ? 0 : sw * (w0 - 1) - pw + KW, OW = tiles_w == 1 ? W : sw * step_w;
+  float b[CI];
+#pragma unroll
+  for (int c = 0; c < CI; ++c) b[c] = bias ? bias[c] : 0.f;
+  const int nth = (KH + sh - 1) / sh, ntw = (KW + sw - 1) / sw;
+  const float inv_ow = 1.0f / (float)OW, inv_sh = 1.0f / (float)sh, inv_sw = 1.0f / (float)sw;
+  for (int o = threadIdx.x; o < OH * OW; o += 256) {
+    const int oy = vg_div_small(o, inv_ow), ox = o - oy * OW;
+    const int hi = hi_lo + oy, wi = wi_lo + ox;
+    if ((unsigned)hi >= (unsigned)H || (unsigned)wi >= (unsigned)W) continue;
+    float sum[CI];
+#pragma unroll
+    for (int c = 0; c < CI; ++c) sum[c] = b[c];
+    // gy rows that reach output row hi: q = floor((hi + ph) / sh) - a with tap kh = hi + ph - q * sh < KH
+    const int qh = vg_div_small(hi + ph, inv_sh), qw = vg_div_small(wi + pw, inv_sw);
+    for (int a = 0; a < nth; ++a) {
+      const int q = qh - a, kh = hi + ph - q * sh;
+      if (kh >= KH || q < 0) break;
+      const int ry = q - h0;
+      if (q >= Ho || (unsigned)ry >= (unsigned)RH) continue;
+      for (int bb = 0; bb < ntw; ++bb) {
+        const int v = qw - bb, kw = wi + pw - v * sw;
+        if (kw >= KW || v < 0) break;
+        const int rx = v - w0;
+        if (v >= Wo || (unsigned)rx >= (unsigned)RW) continue;
+        const float* pp = &part[(ry * RW + rx) * LDP + (kh * KW + kw) * CI];
+#pragma unroll
+        for (int c = 0; c < CI; ++c) sum[c] += pp[c];
+      }
+    }
+    float* op = gx + ((size_t)(n * H + hi) * W + wi) * CI;
+#pragma unroll
+    for (int c = 0; c < CI; ++c) op[c] = sum[c];
+  }
+}
+
 }  // namespace
 
 // Returns 1 if the thin forward kernel took the call, 0 if the shape does not qualify, < 0 on error.
@@ -185,8 +273,60 @@ int vg_thin_dgrad_applies(const vg_conv_geom* g) {
   return g->Ci <= 4 && g->Co % 4 == 0 && thin_dgrad_chunk(g) > 0 && g->sh * g->sw <= 65535;
 }
 
+
+// Tiling of one gy dimension of `extent` pixels for the scatter kernel with `r` tile rows and `nt` = ceil(K/s):
+// one tile from 0 when it covers the dimension, else tiles stepping by r - (nt - 1) from -(nt - 1).
+static void scatter_tiling(int extent, int r, int nt, int* tiles, int* step, int* org) {
+  if (extent <= r) {
+    *tiles = 1; *step = r; *org = 0;
+  } else {
+    *step = r - (nt - 1);
+    *org = -(nt - 1);
+    *tiles = (extent + nt - 1 + *step - 1) / *step;
+  }
+}
+
+static int try_dgrad_scatter(const vg_conv_geom* g, const float* gy, const float* w, const float* bias, float* gx,
+                             hipStream_t st) {
+  const int taps = g->kh * g->kw;
+  if (g->Ci > 4 || g->Co % 4 != 0 || !vg_aligned16(gy) || !vg_aligned16(w)) return 0;
+  if (taps != 9 && taps != 16 && taps != 25) return 0;
+  const int nth = (g->kh + g->sh - 1) / g->sh, ntw = (g->kw + g->sw - 1) / g->sw;
+  // tile shape with the least idle / duplicated threads
+  int best_rw = 0, bt_h = 0, bt_w = 0, bs_h = 0, bs_w = 0, bo_h = 0, bo_w = 0;
+  long long best_blocks = 0;
+  for (int rw = 8; rw <= 64; rw *= 2) {
+    const int rh = 256 / rw;
+    if (rh < nth + 1 && g->Ho > rh) continue;
+    if (rw < ntw + 1 && g->Wo > rw) continue;
+    int th, sh_, oh, tw, sw_, ow;
+    scatter_tiling(g->Ho, rh, nth, &th, &sh_, &oh);
+    scatter_tiling(g->Wo, rw, ntw, &tw, &sw_, &ow);
+    const long long blocks = (long long)th * tw;
+    if (best_rw == 0 || blocks < best_blocks) {
+      best_rw = rw; best_blocks = blocks; bt_h = th; bt_w = tw; bs_h = sh_; bs_w = sw_; bo_h = oh; bo_w = ow;
+    }
+  }
+  if (best_rw == 0) return 0;
+  const long long grid = best_blocks * g->N;
+  if (grid > 0x7fffffffLL) return 0;
+#define THIN_SCATTER(CI_, TAPS_)                                                                                        \
+  if (g->Ci == CI_ && taps == TAPS_)                                                                                    \
+    hipLaunchKernelGGL((dgrad_scatter_kernel<CI_, TAPS_>), dim3((unsigned)grid), dim3(256), 0, st, gy, w, bias, gx,      \
+                       g->H, g->W, g->Co, g->kh, g->kw, g->Ho, g->Wo, g->sh, g->sw, g->ph, g->pw, best_rw, bt_h, bt_w,  \
+                       bs_h, bs_w, bo_h, bo_w);
+  THIN_SCATTER(1, 9) THIN_SCATTER(2, 9) THIN_SCATTER(3, 9) THIN_SCATTER(4, 9)
+  THIN_SCATTER(1, 16) THIN_SCATTER(2, 16) THIN_SCATTER(3, 16) THIN_SCATTER(4, 16)
+  THIN_SCATTER(1, 25) THIN_SCATTER(2, 25) THIN_SCATTER(3, 25) THIN_SCATTER(4, 25)
+#undef THIN_SCATTER
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return vg_fail(VG_ERR_LAUNCH, "vg_conv2d_dgrad(scatter): launch failed: %s", hipGetErrorString(e));
+  return 1;
+}
+
 int vg_try_dgrad_thin(const vg_conv_geom* g, const float* gy, const float* w, const float* bias, float* gx,
                       hipStream_t st) {
+  if (int r = try_dgrad_scatter(g, gy, w, bias, gx, st)) return r;
   if (!vg_thin_dgrad_applies(g) || !vg_aligned16(gy)) return 0;
   int cc = thin_dgrad_chunk(g);
   while (cc > g->Co && cc > 4) cc /= 2;

@@ -29,6 +29,10 @@ CONV_CASES = [
     (2, 11, 32, 32, 8, 5, 2, 2),     # Ci=11 conditional input, 5x5
     (2, 8, 12, 12, 20, 3, 2, 0),     # stride 2, no padding, odd phases
     (130, 4, 4, 4, 36, 1, 1, 0),     # 1x1 conv, M not a tile multiple
+    (2, 3, 9, 7, 8, 3, 1, 1),        # few input channels: scatter-form dgrad, 3x3 stride 1, odd sizes
+    (3, 1, 12, 12, 12, 5, 2, 2),     # Ci=1, 5x5 stride 2
+    (1, 2, 140, 150, 4, 4, 2, 1),    # Ci=2, gradient image larger than one tile in both dimensions
+    (2, 4, 37, 21, 8, 4, 2, 1),      # Ci=4, several row tiles, odd sizes
 ]
 
 
