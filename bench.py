@@ -84,10 +84,14 @@ def main():
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit("--gpus %d needs `python -m torch.distributed.run --nproc-per-node %d bench.py ...`" %
                          (args.gpus, args.gpus))
-    torch.cuda.set_device(local_rank)
+    torch.cuda.set_device(local_rank % max(torch.cuda.device_count(), 1))
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        backend = os.environ.get("VEGANS_BENCH_BACKEND", "nccl")     # "gloo": rehearsal of the N > 1 flow on one GPU
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     from vegans.engine import ops, parallel
 
@@ -116,7 +120,7 @@ def main():
         torch.cuda.synchronize()
 
     # Set-up, like building the model: the first calls of train_on_batch run eagerly and the third records the HIP
-    # graph that later calls replay (single GPU; data-parallel runs stay eager).
+    # graphs that later calls replay (data-parallel runs: a chain of graphs with the gradient all-reduces in between).
     for i in range(SETUP_STEPS):
         step(i)
     for i in range(args.warmup):

@@ -14,11 +14,17 @@ What a replay does, in order, on the current stream:
      streams advance exactly as they do without a graph;
   3. launch the graph.
 
+Under data parallelism the gradient all-reduce is not captured: at that point the capture is cut, so an iteration
+becomes a chain  graph | all-reduce | graph | all-reduce | graph  whose pieces share one memory pool and whose
+collectives are ordinary eager calls on the persistent gradient buckets between two graph launches (no dependence
+on collectives being capturable; communication then no longer overlaps backward, which costs less than the host
+time the graphs save).
+
 Everything a kernel receives by value is frozen into the graph (learning rates, clip value, penalty weight ...), so
 all of it is part of the cache key: a change makes a new graph.  Capture is skipped (the body simply runs eagerly)
-under data parallelism, for optimizers whose kernels take step-dependent host scalars (Adam), for batch norms with
+for optimizers whose kernels take step-dependent host scalars (Adam), for batch norms with
 `momentum=None`, while the benchmark's per-kernel event timer is installed, when the model's `use_step_graph`
-attribute is set to False, or when VEGANS_HIP_GRAPH=0.  A body that
+attribute is set to False, or when VEGANS_HIP_GRAPH=0 (VEGANS_HIP_GRAPH_DP=0: only data-parallel runs stay eager).  A body that
 cannot be captured (user modules that synchronise or branch on device values) falls back to eager for good, with a
 warning.
 """
@@ -60,6 +66,12 @@ def host_input(shape, draw, device):
     return buf
 
 
+def cut(fn):
+    """Only while capturing: end the graph recorded so far, schedule host function `fn` (e.g. a collective on
+    persistent buffers) to run at this point of every replay, and start recording the next graph."""
+    _capturing.cut(fn)
+
+
 def host_effect(fn):
     """Host-side bookkeeping that belongs to one training iteration (e.g. optimizer step counters): run now when
     eager, once per replay when the iteration is being captured."""
@@ -74,6 +86,9 @@ class _StepGraph:
         self.eager_calls = 0
         self.failed = False
         self.graph = None
+        self.segments = []
+        self._cur = None
+        self._pool = None
         self.script = []
         self.static = None
         self.arena = None
@@ -92,31 +107,58 @@ class _StepGraph:
             raise _hip.HipError("host inputs of one training step exceed %d floats" % self.arena.numel())
         return self.arena[start:start + n].view(shape)
 
+    def _begin(self):
+        self._cur = torch.cuda.CUDAGraph()
+        # "thread_local": only this thread is policed for capture-unsafe HIP calls. Communication back-ends keep helper
+        # threads (RCCL watchdog, gloo workers) that poll events at any time; under the default global mode such a
+        # call from another thread fails there and invalidates the capture here.
+        self._cur.capture_begin(pool=self._pool, capture_error_mode="thread_local")
+
+    def _end(self):
+        cur, self._cur = self._cur, None
+        cur.capture_end()
+        self.segments.append(cur)
+
+    def cut(self, fn):
+        self._end()
+        self.segments.append(fn)
+        self._begin()
+
     def capture(self, model, body, inputs):
         global _capturing
         self.static = [torch.empty_like(t) for t in inputs]      # preserves the (NHWC) strides
         for s, t in zip(self.static, inputs):
             s.copy_(t)
         self.script = []
+        self.segments = []     # CUDAGraph objects and host callables, in replay order
         self.arena = torch.empty(HOST_INPUT_FLOATS, dtype=torch.float32, device=inputs[0].device)
         self.arena_used = 0
-        graph = torch.cuda.CUDAGraph()
+        self._pool = torch.cuda.graph_pool_handle()
+        side = torch.cuda.Stream()
+        gc.collect()               # dead models must release their graphs now, not during the capture
         torch.cuda.synchronize()
+        side.wait_stream(torch.cuda.current_stream())
         _capturing = self
         _hip.freeze_workspace(True)
         # No cyclic garbage collection while the stream is capturing: collecting an old model would destroy its graphs
-        # and free their memory pools, which HIP forbids during capture (torch.cuda.graph collects once on entry).
+        # and free their memory pools, which HIP forbids during capture.
         gc_was_enabled = gc.isenabled()
         gc.disable()
         try:
-            with torch.cuda.graph(graph):
-                body(*self.static)
+            with torch.cuda.stream(side):
+                self._begin()
+                try:
+                    body(*self.static)
+                finally:
+                    if self._cur is not None:
+                        self._end()
         finally:
             if gc_was_enabled:
                 gc.enable()
             _capturing = None
             _hip.freeze_workspace(False)
-        self.graph = graph
+        torch.cuda.current_stream().wait_stream(side)
+        self.graph = self.segments[-1]
         # values only: keeping grad_fn would keep this iteration's autograd graph (and its AccumulateGrad nodes, bound
         # to the capture stream) alive into later captures
         self.losses = {k: v.detach() for k, v in model._losses.items()}
@@ -131,7 +173,11 @@ class _StepGraph:
                 fn()
             else:
                 buf.copy_(_stage(fn()), non_blocking=True)
-        self.graph.replay()
+        for seg in self.segments:
+            if isinstance(seg, torch.cuda.CUDAGraph):
+                seg.replay()
+            else:
+                seg()
         model._losses = dict(self.losses)
         for p, g in self.grads:
             p.grad = g
@@ -153,14 +199,21 @@ def _frozen_scalars(model):
     return tuple(sig)
 
 
+def _sharding(model):
+    dp = getattr(model, "_dp", None)
+    if dp is None or dp.world == 1:
+        return (1,)
+    return (dp.world, dp.rank, dp.local_rows, dp.global_rows)
+
+
 def _eligible(model):
     from . import ops
+    dp = getattr(model, "_dp", None)
+    if dp is not None and dp.world > 1 and os.environ.get("VEGANS_HIP_GRAPH_DP", "1") == "0":
+        return False
     if os.environ.get("VEGANS_HIP_GRAPH", "1") == "0" or ops.conv_timer is not None:
         return False
     if not getattr(model, "use_step_graph", True):
-        return False
-    dp = getattr(model, "_dp", None)
-    if (getattr(model, "ngpu", 0) or 0) > 1 or (dp is not None and dp.world > 1):
         return False
     if not all(type(o) in _GRAPHABLE_OPTIMIZERS for o in model.optimizers.values()):
         return False
@@ -178,7 +231,7 @@ def run_step(model, body, inputs):
     if not _eligible(model):
         return body(*inputs)
     key = (tuple((tuple(t.shape), t.stride()) for t in inputs), tuple(sorted(model.steps.items())),
-           _frozen_scalars(model),
+           _frozen_scalars(model), _sharding(model),
            tuple(p.requires_grad for net in model.neural_nets.values() for p in net.parameters()))
     cache = _graphs.setdefault(model, {})
     entry = cache.get(key)

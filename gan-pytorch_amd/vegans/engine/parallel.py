@@ -15,6 +15,7 @@ from ctypes import c_float, c_size_t
 import torch
 import torch.distributed as dist
 
+from . import graph
 from .._hip import _ptr, _stream, call
 
 BUCKETS_PER_NET = 3
@@ -137,20 +138,59 @@ class GradReducer:
         # the optimizer reads the reduced values straight from the bucket, in the parameter's memory order
         p.grad = view.as_strided(p.shape, g.stride())
         self.pending[bi] -= 1
-        if self.pending[bi] == 0:
-            self.works.append(dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True))
+        if self.pending[bi] == 0 and not graph.capturing():
+            self.works.append(_all_reduce_async(flat))
 
     def finish(self):
         """Flush buckets whose parameters got no gradient this time and wait for every all-reduce."""
         if not self.armed:
             return
+        if graph.capturing():
+            # the iteration is being recorded into HIP graphs: nothing was launched from the hooks; cut the recording
+            # here and let every replay all-reduce the buckets that received gradients, between two graph launches
+            flats = [self.flat[bi] for bi, left in enumerate(self.pending) if left < len(self.buckets[bi])]
+            self.armed = False
+            graph.cut(lambda: _all_reduce_now(flats))
+            return
         for bi, left in enumerate(self.pending):
             if 0 < left < len(self.buckets[bi]):
-                self.works.append(dist.all_reduce(self.flat[bi], op=dist.ReduceOp.SUM, async_op=True))
+                self.works.append(_all_reduce_async(self.flat[bi]))
         for w in self.works:
-            w.wait()
+            if w is not None:
+                w.wait()
         self.works = []
         self.armed = False
+
+
+def _gloo():
+    return dist.get_backend() == "gloo"
+
+
+def _all_reduce_async(flat):
+    """Start the sum of one bucket over all ranks; returns a work handle, or None when it already completed. The gloo
+    transport (CPU rehearsals and single-GPU tests; production is RCCL) is fed host copies: its device path runs
+    copies on private streams from helper threads, which proved unreliable next to HIP graph launches."""
+    if _gloo() and flat.is_cuda:
+        host = flat.cpu()
+        dist.all_reduce(host, op=dist.ReduceOp.SUM)
+        flat.copy_(host)
+        return None
+    return dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True)
+
+
+def _all_reduce_now(flats):
+    """All-reduce gradient buckets between two graph launches of a replayed iteration. Blocking collectives (current
+    stream semantics), fenced by device-wide host waits on both sides, so that a graph launch never has a cross-stream
+    event wait pending in front of or behind it: the device is idle when the collective starts and idle again when the
+    next graph is launched. Two fenced collectives per network update cost a few hundred microseconds per iteration,
+    far less than enqueueing the iteration kernel by kernel."""
+    torch.cuda.synchronize()
+    for f in flats:
+        if _gloo() and f.is_cuda:
+            _all_reduce_async(f)
+        else:
+            dist.all_reduce(f, op=dist.ReduceOp.SUM)
+    torch.cuda.synchronize()
 
 
 def arm(model, who):

@@ -1,7 +1,8 @@
 """Data-parallel path on the GPU: two ranks (both on cuda:0, gloo transport, since one box has one GPU) train a
 BatchNorm-free WGAN-GP on a global batch sharded by rows; the result must equal a single-process run on the whole
 batch (the per-rank means weighted by rows/global_rows sum to the global mean), and both ranks must end with
-identical weights."""
+identical weights.  The run is long enough for the iteration to be captured and replayed as HIP graphs on both
+sides."""
 import os
 import subprocess
 import sys
@@ -35,13 +36,21 @@ def run(ngpu, rows):
     with contextlib.redirect_stdout(io.StringIO()):
         m = gan.WassersteinGANGP(G, D, x_dim=(3, 16, 16), z_dim=(8, 1, 1), folder=None, fixed_noise_size=2, ngpu=ngpu,
                                  optim_kwargs={"Generator": {"lr": 1e-3}, "Adversariat": {"lr": 1e-3}})
-    X = cfg.synthetic_images(rows * 3 - 2, (3, 16, 16), seed=3)       # last batch is partial (uneven shards)
+    X = cfg.synthetic_images(rows * 6 - 2, (3, 16, 16), seed=3)       # last batch is partial (uneven shards)
     zgen = torch.Generator().manual_seed(11)
-    zs = iter([torch.randn(rows, 8, 1, 1, generator=zgen) for _ in range(3)])
+    zs = iter([torch.randn(rows, 8, 1, 1, generator=zgen) for _ in range(6)])
     m.sample = lambda n: next(zs)[:n].to("cuda").requires_grad_(True)
     np.random.seed(17)
     with contextlib.redirect_stdout(io.StringIO()):
         m.fit(X, epochs=1, batch_size=rows, print_every=None, save_losses_every=None, enable_tensorboard=False)
+    # batches 1-2 run kernel by kernel, batch 3 is recorded and batches 3-5 replayed: under data parallelism as a
+    # chain of graphs with the bucket all-reduces in between
+    from vegans.engine import graph
+    full = [e for e in graph._graphs[m].values() if e.graph is not None]
+    assert len(full) == 1 and not full[0].failed, [(e.eager_calls, e.failed) for e in graph._graphs[m].values()]
+    n_graphs = sum(isinstance(s, torch.cuda.CUDAGraph) for s in full[0].segments)
+    n_host = len(full[0].segments) - n_graphs
+    assert (n_graphs, n_host) == ((3, 2) if ngpu else (1, 0)), (n_graphs, n_host)
     return [p.detach().cpu().clone() for net in (G, D) for p in net.parameters()]
 
 dp = run(world, 8)
