@@ -55,6 +55,9 @@ SIGNATURES = {
     "vg_conv2d_wgrad_partial": (c_int, [_G, _P, _P, _P, _P, c_size_t, _P]),
     "vg_conv2d_wgrad_reduce": (c_int, [_G, _P, _P, _P]),
     "vg_conv2d_variant": (c_int, [c_int, _G, ctypes.c_char_p, c_size_t]),
+    "vg_maxpool2d_fwd": (c_int, [POINTER(ConvGeom), _P, _P, _P, _P]),
+    "vg_maxpool2d_bwd": (c_int, [POINTER(ConvGeom), _P, _P, _P, _P]),
+    "vg_maxpool2d_pick": (c_int, [POINTER(ConvGeom), _P, _P, _P, _P]),
     "vg_nchw_to_nhwc": (c_int, [_P, _P, c_int, c_int, c_int, _P]),
     "vg_nhwc_to_nchw": (c_int, [_P, _P, c_int, c_int, c_int, _P]),
     "vg_concat_channels": (c_int, [_P, c_int, c_int, _P, c_int, c_int, _P, c_int, c_int, _P]),

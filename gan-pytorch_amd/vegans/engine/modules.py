@@ -86,6 +86,12 @@ class HipSigmoid(nn.Sigmoid):
         return ops.activation(x, _hip.ACT_SIGMOID)
 
 
+class HipMaxPool2d(nn.MaxPool2d):
+    def forward(self, x):
+        return ops.max_pool2d(x, _pair(self.kernel_size), _pair(self.stride if self.stride is not None else self.kernel_size),
+                              _pair(self.padding))
+
+
 class HipFlatten(nn.Flatten):
     def forward(self, x):
         if self.start_dim != 1 or self.end_dim not in (-1, x.dim() - 1):
@@ -140,6 +146,7 @@ _SWAP = {
     nn.Tanh: HipTanh,
     nn.Sigmoid: HipSigmoid,
     nn.Flatten: HipFlatten,
+    nn.MaxPool2d: HipMaxPool2d,
 }
 _STOCK = {v: k for k, v in _SWAP.items()}
 
@@ -148,6 +155,10 @@ _PASS_THROUGH = (nn.Identity, nn.Unflatten)
 
 
 def _validate(m):
+    if isinstance(m, nn.MaxPool2d):
+        if _pair(m.dilation) != (1, 1) or m.ceil_mode or m.return_indices:
+            raise NotImplementedError("MaxPool2d with dilation / ceil_mode / return_indices is not supported by the HIP engine")
+        return
     if isinstance(m, (nn.Conv2d, nn.ConvTranspose2d)):
         if _pair(m.dilation) != (1, 1) or m.groups != 1:
             raise NotImplementedError("%s with dilation/groups is not supported by the HIP engine" % type(m).__name__)

@@ -584,6 +584,61 @@ def activation(x, act, slope=0.0):
 
 
 # ----------------------------------------------------------------------------------------------------------------
+# max pooling
+# ----------------------------------------------------------------------------------------------------------------
+def _iptr(t):
+    return ctypes.c_void_p(t.data_ptr())
+
+
+class MaxPoolFn(Function):
+    @staticmethod
+    def forward(ctx, x, kernel, stride, padding):
+        x = to_nhwc(x)
+        n, c, h, w = x.shape
+        g = Geom(n, h, w, c, c, kernel[0], kernel[1], stride[0], stride[1], padding[0], padding[1])
+        y = _new_act(n, c, g.Ho, g.Wo, x, False)
+        idx = torch.empty((n, c, g.Ho, g.Wo), dtype=torch.int32, device=x.device, memory_format=CL)
+        call("vg_maxpool2d_fwd", ctypes.byref(g.c), _ptr(x), _ptr(y), _iptr(idx), _stream())
+        ctx.g = g
+        ctx.save_for_backward(idx)
+        ctx.mark_non_differentiable(idx)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        (idx,) = ctx.saved_tensors
+        return MaxPoolBwdFn.apply(gy, idx, ctx.g), None, None, None
+
+
+class MaxPoolBwdFn(Function):
+    """gx of max pooling as a (linear) function of gy for fixed winners; its own derivative picks the winners."""
+
+    @staticmethod
+    def forward(ctx, gy, idx, g):
+        gy = to_nhwc(gy)
+        _check_shape(gy, (g.N, g.Ci, g.Ho, g.Wo), "pooling output-side tensor")
+        gx = _new_act(g.N, g.Ci, g.H, g.W, gy, False)
+        call("vg_maxpool2d_bwd", ctypes.byref(g.c), _ptr(gy), _iptr(idx), _ptr(gx), _stream())
+        ctx.g = g
+        ctx.save_for_backward(idx)
+        return gx
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, ggx):
+        (idx,) = ctx.saved_tensors
+        g = ctx.g
+        ggx = to_nhwc(ggx)
+        out = _new_act(g.N, g.Ci, g.Ho, g.Wo, ggx, False)
+        call("vg_maxpool2d_pick", ctypes.byref(g.c), _ptr(ggx), _iptr(idx), _ptr(out), _stream())
+        return out, None, None
+
+
+def max_pool2d(x, kernel, stride, padding):
+    return MaxPoolFn.apply(x, tuple(kernel), tuple(stride), tuple(padding))
+
+
+# ----------------------------------------------------------------------------------------------------------------
 # losses (scalars stay on the device)
 # ----------------------------------------------------------------------------------------------------------------
 def _reduce_ws(n, device):

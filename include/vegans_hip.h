@@ -83,6 +83,17 @@ int vg_conv2d_wgrad_reduce(const vg_conv_geom* g, float* gw, const void* workspa
  * benchmark can attribute event-timed durations to the kernel the profiler lists. */
 int vg_conv2d_variant(int mode, const vg_conv_geom* g, char* buf, size_t len);
 
+/* ---- max pooling -----------------------------------------------------------------------
+ * nn.MaxPool2d(kernel, stride, padding) as the reference's image-to-image critic uses it
+ * (examples/example_image_to_image.py:78-90), over NHWC. The geometry struct is the convolution one with
+ * Co == Ci == channels; Ho/Wo = floor((in + 2p - k)/s) + 1 (no ceil_mode, no dilation). `idx` receives, per
+ * output element, the winning input pixel hi*W + wi (first maximum in (kh, kw) scan order; NaN wins).
+ * vg_maxpool2d_bwd: gx = gradient with respect to x given gy and idx (gather form, deterministic).
+ * vg_maxpool2d_pick: out[n][ho][wo][c] = t[n][idx][c], the derivative of vg_maxpool2d_bwd with respect to gy. */
+int vg_maxpool2d_fwd(const vg_conv_geom* g, const float* x, float* y, int* idx, void* stream);
+int vg_maxpool2d_bwd(const vg_conv_geom* g, const float* gy, const int* idx, float* gx, void* stream);
+int vg_maxpool2d_pick(const vg_conv_geom* g, const float* t, const int* idx, float* out, void* stream);
+
 /* ---- layout ---------------------------------------------------------------------------
  * NCHW <-> NHWC copies at the API boundary (user arrays are NCHW: AbstractGenerativeModel.py:319,
  * :672-674) and the label broadcast-concatenate of vegans/utils/utils.py:52-90. */

@@ -182,6 +182,35 @@ def test_batch_norm_with_fused_activation(gpu, act, training):
     assert modules._fused_act(dut[0], dut[1]) is None
 
 
+@pytest.mark.parametrize("shape,k,s,p", [((3, 8, 13, 11), 5, 2, 2), ((2, 3, 8, 8), 2, 2, 0), ((2, 16, 9, 9), 3, 1, 1)])
+def test_max_pool_first_and_second_order(gpu, shape, k, s, p):
+    """nn.MaxPool2d as the reference's image-to-image critic uses it (kernel 5, stride 2, padding 2), overlapping
+    windows included; the double-backward term (a penalty on the input gradient) goes through the winner pick."""
+    from torch import nn
+    from vegans.engine import modules
+    g = torch.Generator().manual_seed(31)
+    x = torch.randn(shape, generator=g)
+    gy_shape = F.max_pool2d(x, k, s, p).shape
+    gy = torch.randn(gy_shape, generator=g)
+    xr = x.clone().requires_grad_(True)
+    yr = F.max_pool2d(xr, k, s, p)
+    (gxr,) = torch.autograd.grad(yr, xr, gy, create_graph=True)
+    pool = modules.bind(nn.Sequential(nn.MaxPool2d(k, s, p)))
+    xd = x.to(gpu).requires_grad_(True)
+    y = pool(xd)
+    gyd = gy.to(gpu).requires_grad_(True)
+    (gxd,) = torch.autograd.grad(y, xd, gyd, create_graph=True)
+    assert torch.equal(y.detach().cpu(), yr.detach())            # selection, not arithmetic: exact
+    _close(gxd, gxr, what="max pool dx")
+    # second order: d/d(gy) of sum(w * gx) picks w at the winners
+    w = torch.randn(shape, generator=g)
+    gyr = gy.clone().requires_grad_(True)
+    (gxr2,) = torch.autograd.grad(F.max_pool2d(xr, k, s, p), xr, gyr, create_graph=True)
+    (gxr2 * w).sum().backward()
+    (d_gy,) = torch.autograd.grad(gxd, gyd, w.to(gpu))
+    _close(d_gy, gyr.grad, what="max pool second order")
+
+
 def test_batch_norm_eval(gpu):
     from vegans.engine import ops
     g = torch.Generator().manual_seed(3)
