@@ -76,6 +76,9 @@ __global__ void __launch_bounds__(256) adam_kernel(float* __restrict__ param, co
   const size_t stride = (size_t)gridDim.x * blockDim.x;
   const bool do_clamp = c.clamp_lo <= c.clamp_hi;
   const float w1 = 1.f - c.beta1;
+  // step-dependent scalars: by value, or (replayed graphs) from two floats the host refreshes before every launch
+  const float step_size = c.step_scalars ? c.step_scalars[0] : c.step_size;
+  const float bc2_sqrt = c.step_scalars ? c.step_scalars[1] : c.bias_correction2_sqrt;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += stride) {
     float p[VEC], g[VEC], m[VEC], v[VEC], x[VEC];
     if constexpr (VEC == 4) {
@@ -104,11 +107,11 @@ __global__ void __launch_bounds__(256) adam_kernel(float* __restrict__ param, co
       float denom;
       if (mx) {
         x[e] = fmaxf(x[e], v[e]);
-        denom = sqrtf(x[e]) / c.bias_correction2_sqrt + c.eps;
+        denom = sqrtf(x[e]) / bc2_sqrt + c.eps;
       } else {
-        denom = sqrtf(v[e]) / c.bias_correction2_sqrt + c.eps;
+        denom = sqrtf(v[e]) / bc2_sqrt + c.eps;
       }
-      p[e] = p[e] + (-c.step_size * m[e]) / denom;
+      p[e] = p[e] + (-step_size * m[e]) / denom;
       if (do_clamp) p[e] = clamp_keep_nan(p[e], c.clamp_lo, c.clamp_hi);
     }
     if constexpr (VEC == 4) {

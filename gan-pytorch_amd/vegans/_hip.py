@@ -32,7 +32,7 @@ class AdamCfg(Structure):
     _fields_ = [("lr", c_float), ("beta1", c_float), ("beta2", c_float), ("eps", c_float),
                 ("weight_decay", c_float), ("step_size", c_float), ("bias_correction2_sqrt", c_float),
                 ("amsgrad", c_int32), ("decoupled_wd", c_int32), ("grad_scale", c_float),
-                ("clamp_lo", c_float), ("clamp_hi", c_float)]
+                ("clamp_lo", c_float), ("clamp_hi", c_float), ("step_scalars", c_void_p)]
 
 
 class SgdCfg(Structure):

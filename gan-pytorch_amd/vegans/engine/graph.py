@@ -22,7 +22,7 @@ time the graphs save).
 
 Everything a kernel receives by value is frozen into the graph (learning rates, clip value, penalty weight ...), so
 all of it is part of the cache key: a change makes a new graph.  Capture is skipped (the body simply runs eagerly)
-for optimizers whose kernels take step-dependent host scalars (Adam), for batch norms with
+for optimizers without a fused kernel, for batch norms with
 `momentum=None`, while the benchmark's per-kernel event timer is installed, when the model's `use_step_graph`
 attribute is set to False, or when VEGANS_HIP_GRAPH=0 (VEGANS_HIP_GRAPH_DP=0: only data-parallel runs stay eager).  A body that
 cannot be captured (user modules that synchronise or branch on device values) falls back to eager for good, with a
@@ -183,7 +183,7 @@ class _StepGraph:
             p.grad = g
 
 
-_GRAPHABLE_OPTIMIZERS = (torch.optim.RMSprop, torch.optim.SGD)
+_GRAPHABLE_OPTIMIZERS = (torch.optim.RMSprop, torch.optim.SGD, torch.optim.Adam, torch.optim.AdamW)
 
 
 def _frozen_scalars(model):

@@ -9,6 +9,7 @@ update and the optional clamp in a single pass over memory.
 import math
 from ctypes import byref, c_float, c_size_t
 
+import numpy as np
 import torch
 
 from .. import _hip
@@ -90,9 +91,8 @@ def _adam(opt, grad_scale, lo, hi, decoupled):
         sign = -1.0 if group.get("maximize", False) else 1.0
         beta1, beta2 = group["betas"]
         lr = _as_float(group["lr"])
-        for p in group["params"]:
-            if p.grad is None:
-                continue
+        params = [p for p in group["params"] if p.grad is not None]
+        for p in params:
             state = opt.state[p]
             if len(state) == 0:
                 state["step"] = torch.tensor(0.0)
@@ -100,14 +100,36 @@ def _adam(opt, grad_scale, lo, hi, decoupled):
                 state["exp_avg_sq"] = _zeros_like(p)
                 if group["amsgrad"]:
                     state["max_exp_avg_sq"] = _zeros_like(p)
-            state["step"] += 1
-            step = float(state["step"])
+        if not params:
+            continue
+        states = [opt.state[p] for p in params]
+
+        def scalars_of(step):
             # host-side doubles, exactly as torch's single-tensor Adam forms them
-            bias_correction1 = 1 - beta1 ** step
-            bias_correction2 = 1 - beta2 ** step
-            cfg = AdamCfg(lr, beta1, beta2, group["eps"], group["weight_decay"], lr / bias_correction1,
-                          math.sqrt(bias_correction2), 1 if group["amsgrad"] else 0, 1 if decoupled else 0,
-                          sign * grad_scale, lo, hi)
+            return lr / (1 - beta1 ** step), math.sqrt(1 - beta2 ** step)
+
+        shared = None
+        if graph.capturing():
+            # a replayed graph cannot carry step-dependent values: the kernels read them from two device floats that
+            # every replay refreshes, at which moment the step counters advance too
+            if len({float(st["step"]) for st in states}) != 1:
+                raise _hip.HipError("Adam parameters of one group are at different steps")
+
+            def advance(states=states):
+                for st in states:
+                    st["step"] += 1
+                return np.asarray(scalars_of(float(states[0]["step"])), dtype=np.float64)
+
+            shared = graph.host_input((2,), advance, params[0].device)
+        for p, state in zip(params, states):
+            if shared is None:
+                state["step"] += 1
+                step_size, bc2_sqrt = scalars_of(float(state["step"]))
+            else:
+                step_size, bc2_sqrt = 0.0, 1.0
+            cfg = AdamCfg(lr, beta1, beta2, group["eps"], group["weight_decay"], step_size, bc2_sqrt,
+                          1 if group["amsgrad"] else 0, 1 if decoupled else 0, sign * grad_scale, lo, hi,
+                          shared.data_ptr() if shared is not None else None)
             call("vg_adam_step", _ptr(p.data), _ptr(_grad_mem(p)), _ptr(state["exp_avg"]), _ptr(state["exp_avg_sq"]),
                  _ptr(state.get("max_exp_avg_sq")), c_size_t(p.numel()), byref(cfg), _stream())
 

@@ -225,6 +225,8 @@ typedef struct vg_adam_cfg {
   int32_t amsgrad;
   int32_t decoupled_wd;         /* AdamW: p *= 1 - lr*wd before the update */
   float grad_scale, clamp_lo, clamp_hi;
+  const float* step_scalars;    /* null, or device {step_size, bias_correction2_sqrt} overriding the two fields above:
+                                   lets a captured HIP graph be replayed for later steps */
 } vg_adam_cfg;
 int vg_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, float* max_exp_avg_sq,
                  size_t n, const vg_adam_cfg* cfg, void* stream);

@@ -26,7 +26,7 @@ def _model(algo, steps=None, seed=4, **extra):
     torch.manual_seed(seed)
     np.random.seed(seed)
     G = cfg.seeded_init(cfg.dcgan_generator(nz=16, ngf=8, nc=3, size=16), 1, 0.08)
-    D = cfg.seeded_init(cfg.dcgan_critic(ndf=8, nc=3, size=16), 2, 0.08)
+    D = cfg.seeded_init(cfg.dcgan_critic(ndf=8, nc=3, size=16, sigmoid=algo in ("LSGAN", "VanillaGAN")), 2, 0.08)
     okw = {"Generator": {"lr": 1e-3}, "Adversariat": {"lr": 5e-4}}
     m = getattr(gan, algo)(G, D, x_dim=(3, 16, 16), z_dim=(16, 1, 1), optim_kwargs=okw, folder=None,
                            fixed_noise_size=4, **extra)
@@ -73,6 +73,7 @@ def _same(a, b, exact, what):
     ("WassersteinGAN", {"Adversariat": 3}, {"clip_val": 0.02}, True),
     ("WassersteinGAN", None, {}, True),
     ("WassersteinGANGP", None, {}, False),
+    ("LSGAN", {"Generator": 2}, {}, True),          # Adam: step-dependent scalars refreshed per replay
 ])
 def test_replayed_step_matches_eager(gpu, algo, steps, extra, exact):
     import bench_configs as cfg
