@@ -59,8 +59,18 @@ __global__ void __launch_bounds__(256) colreduce_partial(F f, int M, int C, int 
 }
 
 // out[v][c] = sum_b partial[v][b][c]; 16 channels x 16 block-lanes per workgroup, fixed summation order.
-template <int NV>
-__global__ void __launch_bounds__(256) colreduce_final(const float* partial, int nblk, int C, float* out) {
+struct StoreSumsE {   // plain result: out[v][c]
+  float* out;
+  int C;
+  template <int NV>
+  __device__ void operator()(int c, const float (&s)[NV]) const {
+#pragma unroll
+    for (int v = 0; v < NV; ++v) out[(size_t)v * C + c] = s[v];
+  }
+};
+
+template <int NV, class E>
+__global__ void __launch_bounds__(256) colreduce_final(const float* partial, int nblk, int C, E epilogue) {
   __shared__ float red[NV * 256];
   const int cl = threadIdx.x & 15, q = threadIdx.x >> 4;
   const int c = blockIdx.x * 16 + cl;
@@ -78,20 +88,22 @@ __global__ void __launch_bounds__(256) colreduce_final(const float* partial, int
   for (int v = 0; v < NV; ++v) red[v * 256 + threadIdx.x] = acc[v];
   __syncthreads();
   if (q == 0 && c < C) {
+    float tot[NV];
 #pragma unroll
     for (int v = 0; v < NV; ++v) {
       const float* rr = red + v * 256 + cl;
       float s = 0.f;
 #pragma unroll
       for (int j = 0; j < 16; ++j) s += rr[16 * j];
-      out[(size_t)v * C + c] = s;
+      tot[v] = s;
     }
+    epilogue.template operator()<NV>(c, tot);
   }
 }
 
-template <int NV, class F>
-int run_colreduce(const char* who, F f, int M, int C, bool vec_ok, float* out, void* ws, size_t ws_bytes,
-                  hipStream_t st) {
+template <int NV, class F, class E>
+int run_colreduce_with(const char* who, F f, int M, int C, bool vec_ok, E epilogue, void* ws, size_t ws_bytes,
+                       hipStream_t st) {
   const int nb = row_blocks(M);
   const size_t need = (size_t)NV * nb * C * sizeof(float);
   if (!ws || ws_bytes < need) return vg_fail(VG_ERR_WORKSPACE, "%s: workspace of %zu bytes required, got %zu", who, need, ws_bytes);
@@ -102,9 +114,15 @@ int run_colreduce(const char* who, F f, int M, int C, bool vec_ok, float* out, v
   else
     hipLaunchKernelGGL((colreduce_partial<NV, 1, F>), dim3(nb), dim3(256), 0, st, f, M, C, rpb, partial);
   VG_CHECK_LAUNCH(who);
-  hipLaunchKernelGGL((colreduce_final<NV>), dim3((C + 15) / 16), dim3(256), 0, st, (const float*)partial, nb, C, out);
+  hipLaunchKernelGGL((colreduce_final<NV, E>), dim3((C + 15) / 16), dim3(256), 0, st, (const float*)partial, nb, C, epilogue);
   VG_CHECK_LAUNCH(who);
   return VG_OK;
+}
+
+template <int NV, class F>
+int run_colreduce(const char* who, F f, int M, int C, bool vec_ok, float* out, void* ws, size_t ws_bytes,
+                  hipStream_t st) {
+  return run_colreduce_with<NV>(who, f, M, C, vec_ok, StoreSumsE{out, C}, ws, ws_bytes, st);
 }
 
 template <int VEC>
@@ -234,25 +252,31 @@ struct BnDbwdF {  // sum g, sum g*xhat, sum u, sum u*xhat, sum u*g   (g as in Bn
 };
 
 // ---- BatchNorm statistics -------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) bn_finalize_kernel(const float* x, const float* sums /*[2][C]*/, int M, int C,
-                                                          float eps, float momentum, float* mean, float* invstd,
-                                                          float* running_mean, float* running_var) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  const float n = (float)M;
-  const float shift = x[c];
-  const float s1 = sums[c] / n;
-  float var = sums[C + c] / n - s1 * s1;
-  var = var < 0.f ? 0.f : var;
-  const float mu = shift + s1;
-  mean[c] = mu;
-  invstd[c] = 1.0f / sqrtf(var + eps);
-  if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mu;
-  if (running_var) {
-    const float unbiased = M > 1 ? var * (n / (n - 1.f)) : var;
-    running_var[c] = (1.f - momentum) * running_var[c] + momentum * unbiased;
+// Epilogue of the moments reduction: batch mean / inverse std from the shifted sums, running-statistics update and the
+// batch counter, all in the kernel that finishes the reduction.
+struct BnFinalizeE {
+  const float* x;        // first row: the shift of the one-pass moments
+  int M;
+  float eps, momentum;
+  float *mean, *invstd, *running_mean, *running_var;
+  long long* num_batches_tracked;
+  template <int NV>
+  __device__ void operator()(int c, const float (&s)[NV]) const {
+    const float n = (float)M;
+    const float s1 = s[0] / n;
+    float var = s[1] / n - s1 * s1;
+    var = var < 0.f ? 0.f : var;
+    const float mu = x[c] + s1;
+    mean[c] = mu;
+    invstd[c] = 1.0f / sqrtf(var + eps);
+    if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mu;
+    if (running_var) {
+      const float unbiased = M > 1 ? var * (n / (n - 1.f)) : var;
+      running_var[c] = (1.f - momentum) * running_var[c] + momentum * unbiased;
+    }
+    if (num_batches_tracked && c == 0) *num_batches_tracked += 1;
   }
-}
+};
 
 __global__ void __launch_bounds__(256) invstd_kernel(const float* var, float* invstd, int C, float eps) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
@@ -500,19 +524,12 @@ extern "C" int vg_colsum(const float* x, float* out, int M, int C, void* ws, siz
 }
 
 extern "C" int vg_bn_stats(const float* x, int M, int C, float eps, float momentum, float* mean, float* invstd,
-                           float* running_mean, float* running_var, void* ws, size_t ws_bytes, void* stream) {
+                           float* running_mean, float* running_var, long long* num_batches_tracked, void* ws,
+                           size_t ws_bytes, void* stream) {
   VG_REQUIRE(x && mean && invstd && M > 0 && C > 0, "vg_bn_stats: bad arguments");
-  const size_t part = (size_t)2 * row_blocks(M) * C * sizeof(float);
-  const size_t need = part + (size_t)2 * C * sizeof(float);
-  if (!ws || ws_bytes < need) return vg_fail(VG_ERR_WORKSPACE, "vg_bn_stats: workspace of %zu bytes required, got %zu", need, ws_bytes);
-  float* sums = (float*)((char*)ws + part);
   ShiftedMomentsF f{x};
-  hipStream_t st = (hipStream_t)stream;
-  if (int e = run_colreduce<2>("vg_bn_stats", f, M, C, all_aligned({x}), sums, ws, part, st)) return e;
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, st, x, (const float*)sums, M, C, eps, momentum,
-                     mean, invstd, running_mean, running_var);
-  VG_CHECK_LAUNCH("vg_bn_stats");
-  return VG_OK;
+  BnFinalizeE fin{x, M, eps, momentum, mean, invstd, running_mean, running_var, num_batches_tracked};
+  return run_colreduce_with<2>("vg_bn_stats", f, M, C, all_aligned({x}), fin, ws, ws_bytes, (hipStream_t)stream);
 }
 
 extern "C" int vg_bn_invstd_from_var(const float* var, float* invstd, int C, float eps, void* stream) {

@@ -12,13 +12,11 @@ __device__ __forceinline__ float clamp_keep_nan(float v, float lo, float hi) {
   return v > hi ? hi : v;
 }
 
+// one VEC-wide element group i of one tensor
 template <int VEC>
-__global__ void __launch_bounds__(256) rmsprop_kernel(float* __restrict__ param, const float* __restrict__ grad,
-                                                      float* __restrict__ sq, float* __restrict__ mbuf,
-                                                      float* __restrict__ gavg, size_t nvec, vg_rmsprop_cfg c) {
-  const size_t stride = (size_t)gridDim.x * blockDim.x;
-  const bool do_clamp = c.clamp_lo <= c.clamp_hi;
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += stride) {
+__device__ __forceinline__ void rmsprop_update(float* __restrict__ param, const float* __restrict__ grad,
+                                               float* __restrict__ sq, float* __restrict__ mbuf,
+                                               float* __restrict__ gavg, size_t i, const vg_rmsprop_cfg& c, bool do_clamp) {
     float p[VEC], g[VEC], s[VEC], m[VEC], ga[VEC];
     if constexpr (VEC == 4) {
       const f32x4 pv = reinterpret_cast<f32x4*>(param)[i], gv = reinterpret_cast<const f32x4*>(grad)[i],
@@ -66,6 +64,46 @@ __global__ void __launch_bounds__(256) rmsprop_kernel(float* __restrict__ param,
       if (mbuf) mbuf[i] = m[0];
       if (gavg) gavg[i] = ga[0];
     }
+}
+
+template <int VEC>
+__global__ void __launch_bounds__(256) rmsprop_kernel(float* __restrict__ param, const float* __restrict__ grad,
+                                                      float* __restrict__ sq, float* __restrict__ mbuf,
+                                                      float* __restrict__ gavg, size_t nvec, vg_rmsprop_cfg c) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  const bool do_clamp = c.clamp_lo <= c.clamp_hi;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += stride)
+    rmsprop_update<VEC>(param, grad, sq, mbuf, gavg, i, c, do_clamp);
+}
+
+// Many tensors, one launch: block b works on one 8192-element chunk of one tensor (first_block[] is the running
+// count of chunks). A network's update is otherwise a dozen launches of a few microseconds each.
+constexpr int kMultiMax = 24;
+constexpr int kMultiChunk = 8192;
+struct RmspropMulti {
+  float* param[kMultiMax];
+  const float* grad[kMultiMax];
+  float* sq[kMultiMax];
+  float* mbuf[kMultiMax];
+  float* gavg[kMultiMax];
+  unsigned long long n[kMultiMax];
+  int first_block[kMultiMax + 1];
+  int vec[kMultiMax];
+  int count;
+};
+
+__global__ void __launch_bounds__(256) rmsprop_multi_kernel(RmspropMulti t, vg_rmsprop_cfg c) {
+  int k = 0;
+  while (k + 1 < t.count && (int)blockIdx.x >= t.first_block[k + 1]) ++k;    // block-uniform
+  const size_t e0 = (size_t)((int)blockIdx.x - t.first_block[k]) * kMultiChunk;
+  const size_t e1 = e0 + kMultiChunk < t.n[k] ? e0 + kMultiChunk : (size_t)t.n[k];
+  const bool do_clamp = c.clamp_lo <= c.clamp_hi;
+  if (t.vec[k]) {
+    for (size_t i = e0 / 4 + threadIdx.x; i < e1 / 4; i += 256)
+      rmsprop_update<4>(t.param[k], t.grad[k], t.sq[k], t.mbuf[k], t.gavg[k], i, c, do_clamp);
+  } else {
+    for (size_t i = e0 + threadIdx.x; i < e1; i += 256)
+      rmsprop_update<1>(t.param[k], t.grad[k], t.sq[k], t.mbuf[k], t.gavg[k], i, c, do_clamp);
   }
 }
 
@@ -169,6 +207,39 @@ extern "C" int vg_rmsprop_step(float* param, const float* grad, float* square_av
     hipLaunchKernelGGL((rmsprop_kernel<1>), dim3(vg_stream_grid(n, 256)), dim3(256), 0, st, param, grad, square_avg, mb, ga, n,
                        *cfg);
   VG_CHECK_LAUNCH("vg_rmsprop_step");
+  return VG_OK;
+}
+
+extern "C" int vg_rmsprop_step_multi(int count, float* const* params, const float* const* grads, float* const* square_avgs,
+                                     float* const* momentum_bufs, float* const* grad_avgs, const size_t* n,
+                                     const vg_rmsprop_cfg* cfg, void* stream) {
+  VG_REQUIRE(count > 0 && params && grads && square_avgs && n && cfg, "vg_rmsprop_step_multi: bad arguments");
+  VG_REQUIRE(!(cfg->momentum > 0.f) || momentum_bufs, "vg_rmsprop_step_multi: momentum > 0 needs momentum buffers");
+  VG_REQUIRE(!cfg->centered || grad_avgs, "vg_rmsprop_step_multi: centered needs grad_avg buffers");
+  for (int base = 0; base < count; base += kMultiMax) {
+    RmspropMulti t;
+    t.count = count - base < kMultiMax ? count - base : kMultiMax;
+    int blocks = 0;
+    for (int k = 0; k < t.count; ++k) {
+      const int j = base + k;
+      VG_REQUIRE(params[j] && grads[j] && square_avgs[j] && n[j] > 0, "vg_rmsprop_step_multi: null tensor or empty tensor");
+      t.param[k] = params[j];
+      t.grad[k] = grads[j];
+      t.sq[k] = square_avgs[j];
+      t.mbuf[k] = cfg->momentum > 0.f ? momentum_bufs[j] : nullptr;
+      t.gavg[k] = cfg->centered ? grad_avgs[j] : nullptr;
+      VG_REQUIRE(!(cfg->momentum > 0.f) || t.mbuf[k], "vg_rmsprop_step_multi: missing momentum buffer");
+      VG_REQUIRE(!cfg->centered || t.gavg[k], "vg_rmsprop_step_multi: missing grad_avg buffer");
+      t.n[k] = n[j];
+      t.vec[k] = n[j] % 4 == 0 && vg_aligned16(t.param[k]) && vg_aligned16(t.grad[k]) && vg_aligned16(t.sq[k]) &&
+                 (!t.mbuf[k] || vg_aligned16(t.mbuf[k])) && (!t.gavg[k] || vg_aligned16(t.gavg[k]));
+      t.first_block[k] = blocks;
+      blocks += (int)((n[j] + kMultiChunk - 1) / kMultiChunk);
+    }
+    t.first_block[t.count] = blocks;
+    hipLaunchKernelGGL(rmsprop_multi_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, t, *cfg);
+    VG_CHECK_LAUNCH("vg_rmsprop_step_multi");
+  }
   return VG_OK;
 }
 

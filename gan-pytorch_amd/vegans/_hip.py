@@ -70,7 +70,7 @@ SIGNATURES = {
     "vg_fill": (c_int, [_P, c_float, c_size_t, _P]),
     "vg_scalar_combine": (c_int, [_P, c_float, _P, c_float, _P, c_float, _P, _P, _P]),
     "vg_bn_workspace_bytes": (c_size_t, [c_int, c_int]),
-    "vg_bn_stats": (c_int, [_P, c_int, c_int, c_float, c_float, _P, _P, _P, _P, _P, c_size_t, _P]),
+    "vg_bn_stats": (c_int, [_P, c_int, c_int, c_float, c_float, _P, _P, _P, _P, _P, _P, c_size_t, _P]),
     "vg_bn_invstd_from_var": (c_int, [_P, _P, c_int, c_float, _P]),
     "vg_bn_apply": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_float, _P]),
     "vg_bn_bwd_reduce": (c_int, [_P, _P, _P, _P, c_int, c_int, _P, _P, c_size_t, _P, c_int, c_float, _P]),
@@ -96,6 +96,7 @@ SIGNATURES = {
     "vg_gp_penalty_fwd": (c_int, [_P, c_int, _P, _P]),
     "vg_gp_penalty_bwd": (c_int, [_P, _P, _P, _P, c_int, c_size_t, _P]),
     "vg_rmsprop_step": (c_int, [_P, _P, _P, _P, _P, c_size_t, POINTER(RmspropCfg), _P]),
+    "vg_rmsprop_step_multi": (c_int, [c_int, _P, _P, _P, _P, _P, _P, POINTER(RmspropCfg), _P]),
     "vg_adam_step": (c_int, [_P, _P, _P, _P, _P, c_size_t, POINTER(AdamCfg), _P]),
     "vg_sgd_step": (c_int, [_P, _P, _P, c_size_t, POINTER(SgdCfg), _P]),
     "vg_clamp": (c_int, [_P, c_size_t, c_float, c_float, _P]),

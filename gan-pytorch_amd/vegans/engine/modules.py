@@ -37,19 +37,24 @@ class HipLinear(nn.Linear):
 
 class _HipBatchNorm:
     def _hip_forward(self, x, act=_hip.ACT_NONE, slope=0.0):
-        # same bookkeeping as torch.nn.modules.batchnorm._BatchNorm.forward
+        # same bookkeeping as torch.nn.modules.batchnorm._BatchNorm.forward; the batch counter is bumped by the
+        # statistics kernel unless its value is needed on the host first (momentum=None: cumulative average)
+        counter = None
         if self.momentum is None:
             factor = 0.0
         else:
             factor = self.momentum
         if self.training and self.track_running_stats and self.num_batches_tracked is not None:
-            self.num_batches_tracked.add_(1)
             if self.momentum is None:
+                self.num_batches_tracked.add_(1)
                 factor = 1.0 / float(self.num_batches_tracked)
+            else:
+                counter = self.num_batches_tracked
         use_batch_stats = self.training or (self.running_mean is None and self.running_var is None)
         rm = self.running_mean if (not self.training or self.track_running_stats) else None
         rv = self.running_var if (not self.training or self.track_running_stats) else None
-        return ops.batch_norm(x, self.weight, self.bias, rm, rv, use_batch_stats, factor, self.eps, act, slope)
+        return ops.batch_norm(x, self.weight, self.bias, rm, rv, use_batch_stats, factor, self.eps, act, slope,
+                              counter if use_batch_stats else None)
 
 
 class HipBatchNorm2d(nn.BatchNorm2d, _HipBatchNorm):

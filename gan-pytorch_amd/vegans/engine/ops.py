@@ -388,7 +388,7 @@ class BatchNormTrainFn(Function):
     activation the output doubles as the slope mask of the backward pass, so no pre-activation tensor exists."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, running_mean, running_var, momentum, eps, act, slope):
+    def forward(ctx, x, gamma, beta, running_mean, running_var, momentum, eps, act, slope, batches_tracked):
         x_in = x
         x = to_nhwc(x)
         m, c = _rows_cols(x)
@@ -396,7 +396,9 @@ class BatchNormTrainFn(Function):
         invstd = torch.empty(c, dtype=torch.float32, device=x.device)
         ws, nbytes = _bn_ws(m, c, x.device)
         call("vg_bn_stats", _ptr(x), m, c, c_float(eps), c_float(momentum), _ptr(mean), _ptr(invstd),
-             _ptr(running_mean), _ptr(running_var), ctypes.c_void_p(ws.data_ptr()), c_size_t(nbytes), _stream())
+             _ptr(running_mean), _ptr(running_var),
+             ctypes.c_void_p(batches_tracked.data_ptr()) if batches_tracked is not None else None,
+             ctypes.c_void_p(ws.data_ptr()), c_size_t(nbytes), _stream())
         y = torch.empty_like(x)
         call("vg_bn_apply", _ptr(x), _ptr(mean), _ptr(invstd), _ptr(gamma), _ptr(beta), _ptr(y), m, c,
              act, c_float(slope), _stream())
@@ -414,7 +416,7 @@ class BatchNormTrainFn(Function):
         y = ctx.saved_tensors[4] if ctx.act != _hip.ACT_NONE else None
         gx, ggamma, gbeta = BatchNormBwdFn.apply(gy, x, gamma, mean, invstd, y, ctx.act, ctx.slope)
         return (gx, ggamma if ctx.has_affine[0] else None, gbeta if ctx.has_affine[1] else None,
-                None, None, None, None, None, None)
+                None, None, None, None, None, None, None)
 
 
 class BatchNormBwdFn(Function):
@@ -502,12 +504,17 @@ class BatchNormEvalFn(Function):
         return gx, ggamma, gbeta, None, None, None, None, None
 
 
-def batch_norm(x, gamma, beta, running_mean, running_var, training, momentum, eps, act=_hip.ACT_NONE, slope=0.0):
-    """Batch norm with an optional fused ReLU / LeakyReLU (act, slope) behind it."""
+def batch_norm(x, gamma, beta, running_mean, running_var, training, momentum, eps, act=_hip.ACT_NONE, slope=0.0,
+               batches_tracked=None):
+    """Batch norm with an optional fused ReLU / LeakyReLU (act, slope) behind it. `batches_tracked` (training only):
+    the module's int64 device counter, incremented by the statistics kernel."""
     if act not in (_hip.ACT_NONE, _hip.ACT_RELU, _hip.ACT_LRELU):
         raise ValueError("only relu / leaky relu can be fused behind a batch norm")
     if training:
-        return BatchNormTrainFn.apply(x, gamma, beta, running_mean, running_var, momentum, eps, act, float(slope))
+        if batches_tracked is not None and (batches_tracked.dtype != torch.int64 or not batches_tracked.is_cuda):
+            raise _hip.HipError("num_batches_tracked must be an int64 tensor on the GPU")
+        return BatchNormTrainFn.apply(x, gamma, beta, running_mean, running_var, momentum, eps, act, float(slope),
+                                      batches_tracked)
     return BatchNormEvalFn.apply(x, gamma, beta, running_mean, running_var, eps, act, float(slope))
 
 

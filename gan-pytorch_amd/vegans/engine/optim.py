@@ -7,7 +7,7 @@ runs in one kernel per parameter tensor: gradient pre-scale (data-parallel mean)
 update and the optional clamp in a single pass over memory.
 """
 import math
-from ctypes import byref, c_float, c_size_t
+from ctypes import byref, c_float, c_size_t, c_void_p
 
 import numpy as np
 import torch
@@ -62,13 +62,21 @@ def fused_step(optimizer, grad_scale=1.0, clamp=None):
             "optimizer %s has no fused MI355X kernel (supported: RMSprop, Adam, AdamW, SGD)" % kind.__name__)
 
 
+def _pointer_array(tensors):
+    arr = (c_void_p * len(tensors))()
+    for i, t in enumerate(tensors):
+        arr[i] = t.data_ptr() if t is not None else None
+    return arr
+
+
 def _rmsprop(opt, grad_scale, lo, hi):
     for group in opt.param_groups:
         _check_flags(group, "RMSprop")
         sign = -1.0 if group.get("maximize", False) else 1.0
-        for p in group["params"]:
-            if p.grad is None:
-                continue
+        params = [p for p in group["params"] if p.grad is not None]
+        if not params:
+            continue
+        for p in params:
             state = opt.state[p]
             if len(state) == 0:
                 state["step"] = torch.tensor(0.0)
@@ -77,12 +85,19 @@ def _rmsprop(opt, grad_scale, lo, hi):
                     state["momentum_buffer"] = _zeros_like(p)
                 if group["centered"]:
                     state["grad_avg"] = _zeros_like(p)
-            graph.host_effect(lambda st=state: st["step"].add_(1))
-            cfg = RmspropCfg(_as_float(group["lr"]), group["alpha"], group["eps"], group["weight_decay"],
-                             group["momentum"], 1 if group["centered"] else 0, sign * grad_scale, lo, hi)
-            call("vg_rmsprop_step", _ptr(p.data), _ptr(_grad_mem(p)), _ptr(state["square_avg"]),
-                 _ptr(state.get("momentum_buffer")), _ptr(state.get("grad_avg")), c_size_t(p.numel()), byref(cfg),
-                 _stream())
+        states = [opt.state[p] for p in params]
+        graph.host_effect(lambda states=states: [st["step"].add_(1) for st in states])
+        cfg = RmspropCfg(_as_float(group["lr"]), group["alpha"], group["eps"], group["weight_decay"],
+                         group["momentum"], 1 if group["centered"] else 0, sign * grad_scale, lo, hi)
+        grads = [_grad_mem(p) for p in params]
+        for t in grads:
+            _ptr(t)      # device / dtype check
+        sizes = (c_size_t * len(params))(*[p.numel() for p in params])
+        # one launch for the whole group
+        call("vg_rmsprop_step_multi", len(params), _pointer_array([p.data for p in params]), _pointer_array(grads),
+             _pointer_array([st["square_avg"] for st in states]),
+             _pointer_array([st.get("momentum_buffer") for st in states]),
+             _pointer_array([st.get("grad_avg") for st in states]), sizes, byref(cfg), _stream())
 
 
 def _adam(opt, grad_scale, lo, hi, decoupled):

@@ -128,10 +128,11 @@ int vg_scalar_combine(const float* a, float c0, const float* b, float c1, const 
  * x is [M][C] (M = N*H*W pixels). */
 size_t vg_bn_workspace_bytes(int M, int C);
 /* batch statistics: mean[c], invstd[c] = 1/sqrt(biased var + eps); if running_mean/var are non-null they
- * are updated in place: r = (1-momentum)*r + momentum*stat (unbiased variance), as torch does. */
+ * are updated in place: r = (1-momentum)*r + momentum*stat (unbiased variance), as torch does; if
+ * num_batches_tracked (the module's int64 counter, on the device) is non-null it is incremented by one. */
 int vg_bn_stats(const float* x, int M, int C, float eps, float momentum, float* mean, float* invstd,
-                float* running_mean, float* running_var, void* workspace, size_t workspace_bytes,
-                void* stream);
+                float* running_mean, float* running_var, long long* num_batches_tracked, void* workspace,
+                size_t workspace_bytes, void* stream);
 /* invstd[c] = 1/sqrt(var[c] + eps) (eval mode uses the running statistics) */
 int vg_bn_invstd_from_var(const float* var, float* invstd, int C, float eps, void* stream);
 /* y = act((x - mean) * invstd * gamma + beta); gamma/beta nullable (affine=False) */
@@ -218,6 +219,11 @@ typedef struct vg_rmsprop_cfg {
 } vg_rmsprop_cfg;
 int vg_rmsprop_step(float* param, const float* grad, float* square_avg, float* momentum_buf, float* grad_avg,
                     size_t n, const vg_rmsprop_cfg* cfg, void* stream);
+/* The same update for `count` tensors in one launch (host arrays of device pointers and element counts; the
+ * momentum / grad_avg arrays may be null when the configuration does not use them). */
+int vg_rmsprop_step_multi(int count, float* const* params, const float* const* grads, float* const* square_avgs,
+                          float* const* momentum_bufs, float* const* grad_avgs, const size_t* n,
+                          const vg_rmsprop_cfg* cfg, void* stream);
 typedef struct vg_adam_cfg {
   float lr, beta1, beta2, eps, weight_decay;
   float step_size;              /* lr / (1 - beta1^step), computed by the host in double like torch does */
