@@ -3,18 +3,25 @@
 #include "igemm.h"
 
 int vg_gemm_kn(const float* A, const float* B, const float* bias, int bias_mod, float* out, int M, int Ncols, int K,
-               hipStream_t stream);
+               hipStream_t stream, int precision);
 int vg_try_dgrad_thin(const vg_conv_geom* g, const float* gy, const float* w, const float* bias, float* gx,
                       hipStream_t st);
 
 extern "C" int vg_conv2d_dgrad(const vg_conv_geom* g, const float* gy, const float* w, const float* bias,
                                float* gx, void* stream) {
+  return vg_conv2d_dgrad_prec(g, gy, w, bias, gx, VG_PREC_F32, stream);
+}
+
+extern "C" int vg_conv2d_dgrad_prec(const vg_conv_geom* g, const float* gy, const float* w, const float* bias,
+                                    float* gx, int precision, void* stream) {
   if (int e = vg_check_geom(g, "vg_conv2d_dgrad")) return e;
+  if (precision != VG_PREC_F32 && precision != VG_PREC_BF16)
+    return vg_fail(VG_ERR_INVALID, "vg_conv2d_dgrad: unknown precision %d", precision);
   VG_REQUIRE(gy && w && gx, "vg_conv2d_dgrad: null tensor pointer");
 
   // 1x1 gradient image covering the whole input window: one GEMM [N][Co] x [Co][kh*kw*Ci].
   if (g->Ho == 1 && g->Wo == 1 && g->ph == 0 && g->pw == 0 && g->H == g->kh && g->W == g->kw)
-    return vg_gemm_kn(gy, w, bias, g->Ci, gx, g->N, g->kh * g->kw * g->Ci, g->Co, (hipStream_t)stream);
+    return vg_gemm_kn(gy, w, bias, g->Ci, gx, g->N, g->kh * g->kw * g->Ci, g->Co, (hipStream_t)stream, precision);
 
   if (int r = vg_try_dgrad_thin(g, gy, w, bias, gx, (hipStream_t)stream)) return r < 0 ? r : VG_OK;
 
@@ -36,7 +43,7 @@ extern "C" int vg_conv2d_dgrad(const vg_conv_geom* g, const float* gy, const flo
   const int va = (g->Co % 4 == 0 && vg_aligned16(gy)) ? 4 : 1;
   const int vb = (g->Ci % 4 == 0 && vg_aligned16(w)) ? 4 : 1;
   dim3 grid((unsigned)(p.mtiles * p.ntiles), 1, (unsigned)(g->sh * g->sw));
-  if (igemm_launch<MODE_DGRAD, true>(p, bm, bn, va, vb, grid, (hipStream_t)stream) != 0)
+  if (igemm_launch<MODE_DGRAD, true>(p, bm, bn, va, vb, grid, (hipStream_t)stream, precision) != 0)
     return vg_fail(VG_ERR_INVALID, "vg_conv2d_dgrad: no kernel variant for bn=%d va=%d vb=%d", bn, va, vb);
   VG_CHECK_LAUNCH("vg_conv2d_dgrad");
   return VG_OK;

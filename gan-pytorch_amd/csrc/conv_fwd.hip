@@ -20,9 +20,20 @@ int vg_check_geom(const vg_conv_geom* g, const char* who) {
 int vg_try_fwd_thin(const vg_conv_geom* g, const float* x, const float* w, const float* bias, float* y, hipStream_t st);
 int vg_thin_dgrad_applies(const vg_conv_geom* g);
 
-extern "C" int vg_conv2d_fwd(const vg_conv_geom* g, const float* x, const float* w, const float* bias,
-                             float* y, void* stream) {
+static int check_precision(int precision, const char* who) {
+  if (precision != VG_PREC_F32 && precision != VG_PREC_BF16) return vg_fail(VG_ERR_INVALID, "%s: unknown precision %d", who, precision);
+  return 0;
+}
+
+extern "C" int vg_conv2d_fwd(const vg_conv_geom* g, const float* x, const float* w, const float* bias, float* y,
+                             void* stream) {
+  return vg_conv2d_fwd_prec(g, x, w, bias, y, VG_PREC_F32, stream);
+}
+
+extern "C" int vg_conv2d_fwd_prec(const vg_conv_geom* g, const float* x, const float* w, const float* bias,
+                                  float* y, int precision, void* stream) {
   if (int e = vg_check_geom(g, "vg_conv2d_fwd")) return e;
+  if (int e = check_precision(precision, "vg_conv2d_fwd")) return e;
   VG_REQUIRE(x && w && y, "vg_conv2d_fwd: null tensor pointer");
   if (int r = vg_try_fwd_thin(g, x, w, bias, y, (hipStream_t)stream)) return r < 0 ? r : VG_OK;
   IgemmParams p{};
@@ -41,7 +52,7 @@ extern "C" int vg_conv2d_fwd(const vg_conv_geom* g, const float* x, const float*
   const int va = (g->Ci % 4 == 0 && vg_aligned16(x)) ? 4 : 1;
   const int vb = (p.Ktot % 4 == 0 && vg_aligned16(w)) ? 4 : 1;
   dim3 grid((unsigned)(p.mtiles * p.ntiles), 1, 1);
-  if (igemm_launch<MODE_FWD, false>(p, bm, bn, va, vb, grid, (hipStream_t)stream) != 0)
+  if (igemm_launch<MODE_FWD, false>(p, bm, bn, va, vb, grid, (hipStream_t)stream, precision) != 0)
     return vg_fail(VG_ERR_INVALID, "vg_conv2d_fwd: no kernel variant for bn=%d va=%d vb=%d", bn, va, vb);
   VG_CHECK_LAUNCH("vg_conv2d_fwd");
   return VG_OK;
@@ -51,7 +62,7 @@ extern "C" int vg_conv2d_fwd(const vg_conv_geom* g, const float* x, const float*
 // gradient image is 1x1 (ConvTranspose2d applied to a latent vector): every tap then hits exactly one output
 // pixel and the transposed convolution is a single GEMM against the weight viewed as [Co][kh*kw*Ci].
 int vg_gemm_kn(const float* A, const float* B, const float* bias, int bias_mod, float* out, int M, int Ncols, int K,
-               hipStream_t stream) {
+               hipStream_t stream, int precision) {
   IgemmParams p{};
   p.A = A; p.B = B; p.bias = bias; p.out = out;
   p.N = M; p.H = 1; p.W = 1; p.Ci = K; p.Co = Ncols; p.KH = 1; p.KW = 1;
@@ -65,7 +76,7 @@ int vg_gemm_kn(const float* A, const float* B, const float* bias, int bias_mod, 
   const int va = (K % 4 == 0 && vg_aligned16(A)) ? 4 : 1;
   const int vb = (Ncols % 4 == 0 && vg_aligned16(B)) ? 4 : 1;
   dim3 grid((unsigned)(p.mtiles * p.ntiles), 1, 1);
-  if (igemm_launch<MODE_FWD, true>(p, bm, bn, va, vb, grid, stream) != 0)
+  if (igemm_launch<MODE_FWD, true>(p, bm, bn, va, vb, grid, stream, precision) != 0)
     return vg_fail(VG_ERR_INVALID, "vg_gemm_kn: no kernel variant for bn=%d va=%d vb=%d", bn, va, vb);
   VG_CHECK_LAUNCH("vg_gemm_kn");
   return VG_OK;

@@ -97,7 +97,14 @@ extern "C" size_t vg_conv2d_wgrad_workspace_bytes(const vg_conv_geom* g) {
 // Phase 1: the contraction. With more than one split the per-split slabs land in `workspace`, otherwise `gw` is final.
 extern "C" int vg_conv2d_wgrad_partial(const vg_conv_geom* g, const float* gy, const float* x, float* gw, void* workspace,
                                        size_t workspace_bytes, void* stream) {
+  return vg_conv2d_wgrad_partial_prec(g, gy, x, gw, workspace, workspace_bytes, VG_PREC_F32, stream);
+}
+
+extern "C" int vg_conv2d_wgrad_partial_prec(const vg_conv_geom* g, const float* gy, const float* x, float* gw,
+                                            void* workspace, size_t workspace_bytes, int precision, void* stream) {
   if (int e = vg_check_geom(g, "vg_conv2d_wgrad")) return e;
+  if (precision != VG_PREC_F32 && precision != VG_PREC_BF16)
+    return vg_fail(VG_ERR_INVALID, "vg_conv2d_wgrad: unknown precision %d", precision);
   VG_REQUIRE(gy && x && gw, "vg_conv2d_wgrad: null tensor pointer");
   const WgradPlan pl = wgrad_plan(g);
   const size_t need = pl.nsplit > 1 ? (size_t)pl.nsplit * pl.M * pl.Ncols * sizeof(float) : 0;
@@ -118,7 +125,7 @@ extern "C" int vg_conv2d_wgrad_partial(const vg_conv_geom* g, const float* gy, c
   const int va = (g->Co % 4 == 0 && vg_aligned16(gy)) ? 4 : 1;
   const int vb = (g->Ci % 4 == 0 && vg_aligned16(x)) ? 4 : 1;
   dim3 grid((unsigned)(pl.mtiles * pl.ntiles), 1, (unsigned)pl.nsplit);
-  if (igemm_launch<MODE_WGRAD, true>(p, pl.bm, pl.bn, va, vb, grid, (hipStream_t)stream) != 0)
+  if (igemm_launch<MODE_WGRAD, true>(p, pl.bm, pl.bn, va, vb, grid, (hipStream_t)stream, precision) != 0)
     return vg_fail(VG_ERR_INVALID, "vg_conv2d_wgrad: no kernel variant for bn=%d va=%d vb=%d", pl.bn, va, vb);
   VG_CHECK_LAUNCH("vg_conv2d_wgrad");
   return VG_OK;

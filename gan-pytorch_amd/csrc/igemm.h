@@ -15,8 +15,23 @@
 // (ds_read_b32, consecutive lanes -> consecutive banks).  The k order inside a 32-deep step is permuted
 // identically for A and B (lane half h of MFMA j in group s holds k = 8s + 4h + j), which a sum over k
 // allows.
+//
+// PREC = 1 (bf16 mode): the same kernel with the operands rounded to bf16 (round to nearest even) when a tile is
+// written to LDS and v_mfma_f32_32x32x16_bf16 doing the products; tensors in global memory, accumulation and the
+// epilogue stay f32.  A [row][k] tile is then kept as bf16 with a row stride of 40 elements (80 bytes:
+// conflict-free ds_read_b128 of the 8 consecutive k one lane feeds the MFMA); a [k][row] tile is kept as
+// [k/2][row] dwords holding the pair (k, k+1), written 16 bytes at a time and read with four ds_read_b32 per
+// fragment; a thread that loads such a tile owns both rows of a pair.
 #pragma once
+#include <type_traits>
 #include "vg_internal.h"
+
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+enum { PREC_F32 = 0, PREC_BF16 = 1 };
 
 enum { MODE_FWD = 0, MODE_DGRAD = 1, MODE_WGRAD = 2 };
 
@@ -48,9 +63,11 @@ struct IgemmParams {
 #define IGEMM_BK 32
 #define IGEMM_LDK 36
 
-template <int MODE, int BM, int BN, int WAVES_M, bool B_MC, int VA, int VB>
+template <int MODE, int BM, int BN, int WAVES_M, bool B_MC, int VA, int VB, int PREC = PREC_F32>
 __global__ void __launch_bounds__(256) igemm_kernel(const IgemmParams p) {
   constexpr int BK = IGEMM_BK, LDK = IGEMM_LDK;
+  constexpr bool BF = PREC == PREC_BF16;
+  constexpr int LDB = 40;   // bf16 elements per row of a [row][k] bf16 tile
   constexpr int WAVES_N = 4 / WAVES_M;
   constexpr int TM = BM / (WAVES_M * 32), TN = BN / (WAVES_N * 32);
   constexpr bool A_MC = (MODE == MODE_WGRAD);
@@ -58,7 +75,8 @@ __global__ void __launch_bounds__(256) igemm_kernel(const IgemmParams p) {
   static_assert(TM >= 1 && TN >= 1, "tile too small for the wave arrangement");
 
   // two staging buffers: tile t+1 is written while tile t is being read, one barrier per k-step
-  constexpr int A_FLOATS = A_MC ? BK * BM : BM * LDK, B_FLOATS = B_IS_MC ? BK * BN : BN * LDK;
+  constexpr int A_FLOATS = BF ? (A_MC ? (BK / 2) * BM : BM * LDB / 2) : (A_MC ? BK * BM : BM * LDK);
+  constexpr int B_FLOATS = BF ? (B_IS_MC ? (BK / 2) * BN : BN * LDB / 2) : (B_IS_MC ? BK * BN : BN * LDK);
   constexpr int BUF = A_FLOATS + B_FLOATS;
   __shared__ __attribute__((aligned(16))) float smem[2 * BUF];
 
@@ -144,6 +162,17 @@ __global__ void __launch_bounds__(256) igemm_kernel(const IgemmParams p) {
   // ---- B loader state -----------------------------------------------------------------------
   constexpr int RB = BN / 32;
   constexpr int TPRB = BN / 4, RPB = 256 / TPRB, PB = BK / RPB;
+  static_assert(!BF || ((!A_MC || PA % 2 == 0) && (!B_IS_MC || PB % 2 == 0)), "bf16 [k][row] tiles pair adjacent k rows");
+  // k row (inside a 32-deep step) of the i-th 16-byte load of a [k][row] tile; in bf16 mode loads 2j and 2j+1 of a
+  // thread are the two rows of one packed pair
+  auto krowA = [&](int i) -> int {
+    if constexpr (BF) return 2 * (tid / TPRA) + (i & 1) + 2 * RPA * (i >> 1);
+    else return tid / TPRA + RPA * i;
+  };
+  auto krowB = [&](int i) -> int {
+    if constexpr (BF) return 2 * (tid / TPRB) + (i & 1) + 2 * RPB * (i >> 1);
+    else return tid / TPRB + RPB * i;
+  };
   // wgrad: the tile columns (kh,kw,ci) of this thread never change along k
   int b_ta[(MODE == MODE_WGRAD) ? VB == 4 ? 1 : 4 : 1], b_tb[(MODE == MODE_WGRAD) ? VB == 4 ? 1 : 4 : 1],
       b_ci[(MODE == MODE_WGRAD) ? VB == 4 ? 1 : 4 : 1];
@@ -179,7 +208,7 @@ __global__ void __launch_bounds__(256) igemm_kernel(const IgemmParams p) {
   if constexpr (MODE == MODE_DGRAD) {
 #pragma unroll
     for (int i = 0; i < PB; ++i) {
-      const int k = kbeg + tid / TPRB + RPB * i;
+      const int k = kbeg + krowB(i);
       bk_t[i] = k / p.Co;
       bk_co[i] = k - bk_t[i] * p.Co;
     }
@@ -191,7 +220,7 @@ __global__ void __launch_bounds__(256) igemm_kernel(const IgemmParams p) {
   if constexpr (MODE == MODE_WGRAD) {
 #pragma unroll
     for (int i = 0; i < PB; ++i) {
-      const int pix = kbeg + tid / TPRB + RPB * i;
+      const int pix = kbeg + krowB(i);
       bp_row[i] = pix / p.Wo;
       bp_wo[i] = pix - bp_row[i] * p.Wo;
     }
@@ -264,7 +293,7 @@ __global__ void __launch_bounds__(256) igemm_kernel(const IgemmParams p) {
       const int m4 = m0 + 4 * (tid % TPRA);
 #pragma unroll
       for (int i = 0; i < PA; ++i) {
-        const int pix = kb + tid / TPRA + RPA * i;
+        const int pix = kb + krowA(i);
         if constexpr (VA == 4) {
           ra[i] = ld4(p.A, (size_t)pix * p.Co + m4, pix < kend && m4 < p.Co);
         } else {
@@ -301,7 +330,7 @@ __global__ void __launch_bounds__(256) igemm_kernel(const IgemmParams p) {
       // plain GEMM operand B[k][n] (row stride Ncols)
 #pragma unroll
       for (int i = 0; i < PB; ++i) {
-        const int k = kb + tid / TPRB + RPB * i;
+        const int k = kb + krowB(i);
         if constexpr (VB == 4) {
           rb[i] = ld4(p.B, (size_t)k * p.Ncols + bn4, k < kend && bn4 < p.Ncols);
         } else {
@@ -318,7 +347,7 @@ __global__ void __launch_bounds__(256) igemm_kernel(const IgemmParams p) {
       // weights w[co][kh][kw][ci] read as B[k=(tap,co)][n=ci]
 #pragma unroll
       for (int i = 0; i < PB; ++i) {
-        const int k = kb + tid / TPRB + RPB * i;
+        const int k = kb + krowB(i);
         const int bta = vg_div_small(bk_t[i], inv_ntw), btb = bk_t[i] - bta * ntw;
         const int kh = cls_h + p.sh * bta, kw = cls_w + p.sw * btb;
         const size_t base = ((size_t)(bk_co[i] * p.KH + kh) * p.KW + kw) * p.Ci;
@@ -338,7 +367,7 @@ __global__ void __launch_bounds__(256) igemm_kernel(const IgemmParams p) {
       // wgrad B = x window, tile [k=pixel][n=(kh,kw,ci)]
 #pragma unroll
       for (int i = 0; i < PB; ++i) {
-        const int pix = kb + tid / TPRB + RPB * i;
+        const int pix = kb + krowB(i);
         const int bpn = vg_div_small(bp_row[i], inv_ho), bpho = bp_row[i] - bpn * p.Ho;
         const int hb = bpho * p.sh - p.ph, wb = bp_wo[i] * p.sw - p.pw;
         if constexpr (VB == 4) {
@@ -390,23 +419,58 @@ __global__ void __launch_bounds__(256) igemm_kernel(const IgemmParams p) {
   auto store_tiles = [&](int buf) {
     float* As = smem + buf * BUF;
     float* Bs = As + A_FLOATS;
-    if constexpr (!A_MC) {
+    if constexpr (!BF) {
+      if constexpr (!A_MC) {
 #pragma unroll
-      for (int i = 0; i < RA; ++i)
-        *reinterpret_cast<f32x4*>(&As[((tid >> 3) + 32 * i) * LDK + 4 * (tid & 7)]) = ra[i];
+        for (int i = 0; i < RA; ++i)
+          *reinterpret_cast<f32x4*>(&As[((tid >> 3) + 32 * i) * LDK + 4 * (tid & 7)]) = ra[i];
+      } else {
+#pragma unroll
+        for (int i = 0; i < PA; ++i)
+          *reinterpret_cast<f32x4*>(&As[(tid / TPRA + RPA * i) * BM + 4 * (tid % TPRA)]) = ra[i];
+      }
+      if constexpr (!B_IS_MC) {
+#pragma unroll
+        for (int i = 0; i < RB; ++i)
+          *reinterpret_cast<f32x4*>(&Bs[((tid >> 3) + 32 * i) * LDK + 4 * (tid & 7)]) = rb[i];
+      } else {
+#pragma unroll
+        for (int i = 0; i < PB; ++i)
+          *reinterpret_cast<f32x4*>(&Bs[(tid / TPRB + RPB * i) * BN + 4 * (tid % TPRB)]) = rb[i];
+      }
     } else {
+      auto pack = [](float lo, float hi) -> unsigned int {
+        const bf16x2 v = {(__bf16)lo, (__bf16)hi};
+        return __builtin_bit_cast(unsigned int, v);
+      };
+      if constexpr (!A_MC) {
+        __bf16* Ah = reinterpret_cast<__bf16*>(As);
 #pragma unroll
-      for (int i = 0; i < PA; ++i)
-        *reinterpret_cast<f32x4*>(&As[(tid / TPRA + RPA * i) * BM + 4 * (tid % TPRA)]) = ra[i];
-    }
-    if constexpr (!B_IS_MC) {
+        for (int i = 0; i < RA; ++i)
+          *reinterpret_cast<bf16x4*>(&Ah[((tid >> 3) + 32 * i) * LDB + 4 * (tid & 7)]) = __builtin_convertvector(ra[i], bf16x4);
+      } else {
+        unsigned int* Au = reinterpret_cast<unsigned int*>(As);
 #pragma unroll
-      for (int i = 0; i < RB; ++i)
-        *reinterpret_cast<f32x4*>(&Bs[((tid >> 3) + 32 * i) * LDK + 4 * (tid & 7)]) = rb[i];
-    } else {
+        for (int i = 0; i + 1 < PA; i += 2) {
+          const u32x4 v = {pack(ra[i][0], ra[i + 1][0]), pack(ra[i][1], ra[i + 1][1]), pack(ra[i][2], ra[i + 1][2]),
+                           pack(ra[i][3], ra[i + 1][3])};
+          *reinterpret_cast<u32x4*>(&Au[(krowA(i) >> 1) * BM + 4 * (tid % TPRA)]) = v;
+        }
+      }
+      if constexpr (!B_IS_MC) {
+        __bf16* Bh = reinterpret_cast<__bf16*>(Bs);
 #pragma unroll
-      for (int i = 0; i < PB; ++i)
-        *reinterpret_cast<f32x4*>(&Bs[(tid / TPRB + RPB * i) * BN + 4 * (tid % TPRB)]) = rb[i];
+        for (int i = 0; i < RB; ++i)
+          *reinterpret_cast<bf16x4*>(&Bh[((tid >> 3) + 32 * i) * LDB + 4 * (tid & 7)]) = __builtin_convertvector(rb[i], bf16x4);
+      } else {
+        unsigned int* Bu = reinterpret_cast<unsigned int*>(Bs);
+#pragma unroll
+        for (int i = 0; i + 1 < PB; i += 2) {
+          const u32x4 v = {pack(rb[i][0], rb[i + 1][0]), pack(rb[i][1], rb[i + 1][1]), pack(rb[i][2], rb[i + 1][2]),
+                           pack(rb[i][3], rb[i + 1][3])};
+          *reinterpret_cast<u32x4*>(&Bu[(krowB(i) >> 1) * BN + 4 * (tid % TPRB)]) = v;
+        }
+      }
     }
   };
 
@@ -418,42 +482,81 @@ __global__ void __launch_bounds__(256) igemm_kernel(const IgemmParams p) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.f;
 
-  // Fragments of one 8-deep slice of a staged tile, and the 4 * TM * TN MFMAs that consume them. The two are separate
-  // so the reads of slice s+1 are in flight while the MFMAs of slice s run (two fragment register sets): a block
-  // that is alone on its CU has no other wave to hide the LDS latency behind.
-  auto load_frags = [&](const float* As, const float* Bs, int s, f32x4 (&af)[TM], f32x4 (&bf)[TN]) {
+  // Fragments of one slice of a staged tile (f32: 8 deep, 4 per k-step; bf16: 16 deep, 2 per k-step) and the MFMAs
+  // that consume them. The two are separate so the reads of slice s+1 are in flight while the MFMAs of slice s run
+  // (two fragment register sets): a block that is alone on its CU has no other wave to hide the LDS latency behind.
+  using Frag = std::conditional_t<BF, bf16x8, f32x4>;
+  auto load_frags = [&](const float* As, const float* Bs, int s, Frag (&af)[TM], Frag (&bf)[TN]) {
+    if constexpr (!BF) {
 #pragma unroll
-    for (int mi = 0; mi < TM; ++mi) {
-      const int row = (wm * TM + mi) * 32 + r;
-      if constexpr (!A_MC) {
-        af[mi] = *reinterpret_cast<const f32x4*>(&As[row * LDK + 8 * s + 4 * h]);
-      } else {
+      for (int mi = 0; mi < TM; ++mi) {
+        const int row = (wm * TM + mi) * 32 + r;
+        if constexpr (!A_MC) {
+          af[mi] = *reinterpret_cast<const f32x4*>(&As[row * LDK + 8 * s + 4 * h]);
+        } else {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) af[mi][j] = As[(8 * s + 4 * h + j) * BM + row];
+          for (int j = 0; j < 4; ++j) af[mi][j] = As[(8 * s + 4 * h + j) * BM + row];
+        }
       }
-    }
 #pragma unroll
-    for (int ni = 0; ni < TN; ++ni) {
-      const int col = (wn * TN + ni) * 32 + r;
-      if constexpr (!B_IS_MC) {
-        bf[ni] = *reinterpret_cast<const f32x4*>(&Bs[col * LDK + 8 * s + 4 * h]);
-      } else {
+      for (int ni = 0; ni < TN; ++ni) {
+        const int col = (wn * TN + ni) * 32 + r;
+        if constexpr (!B_IS_MC) {
+          bf[ni] = *reinterpret_cast<const f32x4*>(&Bs[col * LDK + 8 * s + 4 * h]);
+        } else {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) bf[ni][j] = Bs[(8 * s + 4 * h + j) * BN + col];
+          for (int j = 0; j < 4; ++j) bf[ni][j] = Bs[(8 * s + 4 * h + j) * BN + col];
+        }
+      }
+    } else {
+      // lane (r, h) feeds k = 16 s + 8 h + 0..7
+#pragma unroll
+      for (int mi = 0; mi < TM; ++mi) {
+        const int row = (wm * TM + mi) * 32 + r;
+        if constexpr (!A_MC) {
+          af[mi] = *reinterpret_cast<const bf16x8*>(&reinterpret_cast<const __bf16*>(As)[row * LDB + 16 * s + 8 * h]);
+        } else {
+          const unsigned int* Au = reinterpret_cast<const unsigned int*>(As);
+          u32x4 d;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) d[j] = Au[(8 * s + 4 * h + j) * BM + row];
+          af[mi] = __builtin_bit_cast(bf16x8, d);
+        }
+      }
+#pragma unroll
+      for (int ni = 0; ni < TN; ++ni) {
+        const int col = (wn * TN + ni) * 32 + r;
+        if constexpr (!B_IS_MC) {
+          bf[ni] = *reinterpret_cast<const bf16x8*>(&reinterpret_cast<const __bf16*>(Bs)[col * LDB + 16 * s + 8 * h]);
+        } else {
+          const unsigned int* Bu = reinterpret_cast<const unsigned int*>(Bs);
+          u32x4 d;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) d[j] = Bu[(8 * s + 4 * h + j) * BN + col];
+          bf[ni] = __builtin_bit_cast(bf16x8, d);
+        }
       }
     }
   };
-  auto mma_frags = [&](const f32x4 (&af)[TM], const f32x4 (&bf)[TN]) {
+  auto mma_frags = [&](const Frag (&af)[TM], const Frag (&bf)[TN]) {
+    if constexpr (!BF) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < TN; ++ni)
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mi][j], bf[ni][j], acc[mi][ni], 0, 0, 0);
+    } else {
 #pragma unroll
       for (int mi = 0; mi < TM; ++mi)
 #pragma unroll
         for (int ni = 0; ni < TN; ++ni)
-          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mi][j], bf[ni][j], acc[mi][ni], 0, 0, 0);
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mi], bf[ni], acc[mi][ni], 0, 0, 0);
+    }
   };
 
-  f32x4 afx[TM], bfx[TN], afy[TM], bfy[TN];
+  Frag afx[TM], bfx[TN], afy[TM], bfy[TN];
 
   // One k-step on buffer `buf`. On entry afx/bfx hold slice 0 of that buffer and the staging registers hold tile
   // kt+1, whose global loads were issued a whole k-step ago. Mid-step that tile is written to the other buffer (last
@@ -465,14 +568,18 @@ __global__ void __launch_bounds__(256) igemm_kernel(const IgemmParams p) {
     load_frags(As, Bs, 1, afy, bfy);
     __builtin_amdgcn_sched_barrier(0);
     mma_frags(afx, bfx);
-    load_frags(As, Bs, 2, afx, bfx);
-    __builtin_amdgcn_sched_barrier(0);
-    mma_frags(afy, bfy);
+    if constexpr (!BF) {
+      load_frags(As, Bs, 2, afx, bfx);
+      __builtin_amdgcn_sched_barrier(0);
+      mma_frags(afy, bfy);
+    }
     if (kt + 1 < nk) store_tiles(buf ^ 1);
     if (kt + 2 < nk) load_tiles();
-    load_frags(As, Bs, 3, afy, bfy);
-    __builtin_amdgcn_sched_barrier(0);
-    mma_frags(afx, bfx);
+    if constexpr (!BF) {
+      load_frags(As, Bs, 3, afy, bfy);
+      __builtin_amdgcn_sched_barrier(0);
+      mma_frags(afx, bfx);
+    }
     __syncthreads();
     if (kt + 1 < nk) {
       const float* An = smem + (buf ^ 1) * BUF;
@@ -529,14 +636,23 @@ __global__ void __launch_bounds__(256) igemm_kernel(const IgemmParams p) {
   }
 }
 
-// Launch one (BM, BN, VA, VB) variant chosen at run time; the wave arrangement follows the tile.
+// Launch one (BM, BN, VA, VB) variant chosen at run time; the wave arrangement follows the tile. prec = PREC_BF16 is
+// served for 16-byte-vector operands on the tiles that keep [k][row] pairs whole, anything else runs in f32.
 template <int MODE, bool B_MC>
-static inline int igemm_launch(const IgemmParams& p, int bm, int bn, int va, int vb, dim3 grid, hipStream_t st) {
-#define IGEMM_CASE(BM_, BN_, WM_, VA_, VB_)                                                          \
-  if (bm == BM_ && bn == BN_ && va == VA_ && vb == VB_) {                                            \
-    hipLaunchKernelGGL((igemm_kernel<MODE, BM_, BN_, WM_, B_MC, VA_, VB_>), grid, dim3(256), 0, st, p); \
-    return 0;                                                                                        \
+static inline int igemm_launch(const IgemmParams& p, int bm, int bn, int va, int vb, dim3 grid, hipStream_t st,
+                               int prec = PREC_F32) {
+#define IGEMM_CASE_P(BM_, BN_, WM_, VA_, VB_, P_)                                                          \
+  if (bm == BM_ && bn == BN_ && va == VA_ && vb == VB_) {                                                  \
+    hipLaunchKernelGGL((igemm_kernel<MODE, BM_, BN_, WM_, B_MC, VA_, VB_, P_>), grid, dim3(256), 0, st, p); \
+    return 0;                                                                                              \
   }
+  if (prec == PREC_BF16 && va == 4 && vb == 4) {
+    IGEMM_CASE_P(128, 128, 2, 4, 4, PREC_BF16)
+    IGEMM_CASE_P(128, 64, 2, 4, 4, PREC_BF16)
+    IGEMM_CASE_P(64, 128, 2, 4, 4, PREC_BF16)
+    IGEMM_CASE_P(64, 64, 2, 4, 4, PREC_BF16)
+  }
+#define IGEMM_CASE(BM_, BN_, WM_, VA_, VB_) IGEMM_CASE_P(BM_, BN_, WM_, VA_, VB_, PREC_F32)
 #define IGEMM_TILE(BM_, BN_, WM_) \
   IGEMM_CASE(BM_, BN_, WM_, 4, 4) IGEMM_CASE(BM_, BN_, WM_, 4, 1) IGEMM_CASE(BM_, BN_, WM_, 1, 4) IGEMM_CASE(BM_, BN_, WM_, 1, 1)
   IGEMM_TILE(128, 128, 2)
@@ -546,6 +662,7 @@ static inline int igemm_launch(const IgemmParams& p, int bm, int bn, int va, int
   IGEMM_TILE(64, 64, 2)
 #undef IGEMM_TILE
 #undef IGEMM_CASE
+#undef IGEMM_CASE_P
   return -1;
 }
 

@@ -199,6 +199,11 @@ def _frozen_scalars(model):
     return tuple(sig)
 
 
+def _ops_precision():
+    from . import ops
+    return ops.matmul_precision()
+
+
 def _sharding(model):
     dp = getattr(model, "_dp", None)
     if dp is None or dp.world == 1:
@@ -231,7 +236,7 @@ def run_step(model, body, inputs):
     if not _eligible(model):
         return body(*inputs)
     key = (tuple((tuple(t.shape), t.stride()) for t in inputs), tuple(sorted(model.steps.items())),
-           _frozen_scalars(model), _sharding(model),
+           _frozen_scalars(model), _sharding(model), _ops_precision(),
            tuple(p.requires_grad for net in model.neural_nets.values() for p in net.parameters()))
     cache = _graphs.setdefault(model, {})
     entry = cache.get(key)

@@ -14,6 +14,7 @@ are kept channels_last as well ([Co][kh][kw][Ci] in memory).  Tensors that arriv
 re-laid-out by the layout kernels, never by torch.
 """
 import ctypes
+import os
 from ctypes import c_float, c_int, c_size_t
 
 import torch
@@ -183,6 +184,26 @@ class inputs_only:
         inputs_only.active = self.prev
 
 
+PRECISIONS = {"fp32": 0, "f32": 0, "float32": 0, "bf16": 1, "bfloat16": 1}
+_precision = PRECISIONS[os.environ.get("VEGANS_HIP_PRECISION", "fp32").lower()]
+
+
+def set_matmul_precision(name):
+    """Multiplier precision of the convolution / linear contractions: "fp32" (default; exact f32 products, the mode
+    the parity statements are made for) or "bf16" (operands rounded to bf16 inside the matrix cores, f32
+    accumulation; activations, weights, optimizer state and every other kernel stay f32). Returns the previous name."""
+    global _precision
+    if name not in PRECISIONS:
+        raise ValueError("precision must be one of %s" % sorted(PRECISIONS))
+    previous = "bf16" if _precision == 1 else "fp32"
+    _precision = PRECISIONS[name]
+    return previous
+
+
+def matmul_precision():
+    return "bf16" if _precision == 1 else "fp32"
+
+
 def _launch_conv(mode, g, fn):
     if conv_timer is None:
         fn()
@@ -196,8 +217,8 @@ def raw_conv_fwd(g, x, w, bias):
     if w.numel() != g.w_numel():
         raise _hip.HipError("weight has %d elements, geometry expects %d" % (w.numel(), g.w_numel()))
     y = _new_act(g.N, g.Co, g.Ho, g.Wo, x, g.flat)
-    _launch_conv(0, g, lambda: call("vg_conv2d_fwd", ctypes.byref(g.c), _ptr(x), _ptr(w), _ptr(bias), _ptr(y),
-                                    _stream()))
+    _launch_conv(0, g, lambda: call("vg_conv2d_fwd_prec", ctypes.byref(g.c), _ptr(x), _ptr(w), _ptr(bias), _ptr(y),
+                                    _precision, _stream()))
     return y
 
 
@@ -207,8 +228,8 @@ def raw_conv_dgrad(g, gy, w, bias):
     if w.numel() != g.w_numel():
         raise _hip.HipError("weight has %d elements, geometry expects %d" % (w.numel(), g.w_numel()))
     gx = _new_act(g.N, g.Ci, g.H, g.W, gy, g.flat)
-    _launch_conv(1, g, lambda: call("vg_conv2d_dgrad", ctypes.byref(g.c), _ptr(gy), _ptr(w), _ptr(bias), _ptr(gx),
-                                    _stream()))
+    _launch_conv(1, g, lambda: call("vg_conv2d_dgrad_prec", ctypes.byref(g.c), _ptr(gy), _ptr(w), _ptr(bias), _ptr(gx),
+                                    _precision, _stream()))
     return gx
 
 
@@ -225,8 +246,8 @@ def raw_conv_wgrad(g, gy, x, w_shape):
     nbytes = _hip.load().vg_conv2d_wgrad_workspace_bytes(ctypes.byref(g.c))
     ws = workspace(nbytes, x.device) if nbytes else None
     wsp = ctypes.c_void_p(ws.data_ptr()) if ws is not None else None
-    _launch_conv(2, g, lambda: call("vg_conv2d_wgrad_partial", ctypes.byref(g.c), _ptr(gy), _ptr(x), _ptr(gw), wsp,
-                                    c_size_t(nbytes), _stream()))
+    _launch_conv(2, g, lambda: call("vg_conv2d_wgrad_partial_prec", ctypes.byref(g.c), _ptr(gy), _ptr(x), _ptr(gw), wsp,
+                                    c_size_t(nbytes), _precision, _stream()))
     if nbytes:
         call("vg_conv2d_wgrad_reduce", ctypes.byref(g.c), _ptr(gw), wsp, _stream())
     return gw

@@ -78,6 +78,19 @@ int vg_conv2d_wgrad_partial(const vg_conv_geom* g, const float* gy, const float*
                             void* workspace, size_t workspace_bytes, void* stream);
 int vg_conv2d_wgrad_reduce(const vg_conv_geom* g, float* gw, const void* workspace, void* stream);
 
+/* The same three contractions with a choice of multiplier precision (the north-star configuration names a bf16 mode
+ * next to fp32): VG_PREC_F32 = exact f32 products (what the un-suffixed entry points do); VG_PREC_BF16 = operands
+ * rounded to bf16 (nearest even) on their way into the matrix cores, f32 accumulation, f32 tensors in memory.
+ * Shapes the bf16 tiles do not cover (operands that are not 16-byte vectors, e.g. a 3-channel image stem, and the
+ * bandwidth-bound thin kernels) run in f32 under either setting. */
+enum { VG_PREC_F32 = 0, VG_PREC_BF16 = 1 };
+int vg_conv2d_fwd_prec(const vg_conv_geom* g, const float* x, const float* w, const float* bias, float* y,
+                       int precision, void* stream);
+int vg_conv2d_dgrad_prec(const vg_conv_geom* g, const float* gy, const float* w, const float* bias, float* gx,
+                         int precision, void* stream);
+int vg_conv2d_wgrad_partial_prec(const vg_conv_geom* g, const float* gy, const float* x, float* gw, void* workspace,
+                                 size_t workspace_bytes, int precision, void* stream);
+
 /* Name of the kernel template instance the call for (mode, geometry) dispatches to (mode 0 fwd, 1 dgrad, 2 wgrad;
  * 16-byte aligned tensors assumed), as a kernel trace prints it.  No counterpart in the reference: it exists so a
  * benchmark can attribute event-timed durations to the kernel the profiler lists. */

@@ -60,6 +60,71 @@ def test_conv2d_fwd_bwd(gpu, case):
     _close(bd.grad, br.grad, what="conv bias grad")
 
 
+BF16_CASES = [
+    # kind, N, Cin, H, W, Cout, k, s, p
+    ("conv", 2, 64, 16, 16, 128, 4, 2, 1),     # 128x128 tiles, all three modes
+    ("conv", 3, 16, 9, 7, 24, 3, 1, 1),        # ragged tiles, 3x3 stride 1
+    ("conv", 130, 4, 4, 4, 36, 1, 1, 0),       # 1x1, M not a tile multiple, tiny K
+    ("conv", 2, 8, 12, 12, 20, 3, 2, 0),       # stride 2 without padding: parity classes of different size
+    ("convT", 4, 100, 1, 1, 64, 4, 1, 0),      # latent vector -> 4x4: plain-GEMM path
+    ("convT", 2, 64, 4, 4, 32, 4, 2, 1),       # DCGAN upsample: dgrad kernel as forward
+    ("convT", 2, 20, 4, 4, 12, 5, 3, 1),       # stride 3, k = 5
+]
+
+
+@pytest.mark.parametrize("case", BF16_CASES)
+def test_bf16_mode_is_exact_on_bf16_representable_operands(gpu, case):
+    """bf16 mode rounds the operands to bf16 inside the kernel and accumulates their exact products in f32. Fed with
+    operands that already are bf16 values, every contraction (forward, input gradient, weight gradient) must therefore
+    agree with torch's f32 result to summation-order noise, like the f32 kernels do."""
+    from vegans.engine import ops
+    kind, N, Ci, H, W, Co, k, s, p = case
+    g = torch.Generator().manual_seed(sum(case[1:]))
+    rnd = lambda t: t.bfloat16().float()
+    x = rnd(torch.randn(N, Ci, H, W, generator=g))
+    if kind == "conv":
+        w = rnd(torch.randn(Co, Ci, k, k, generator=g) * 0.1)
+        ref = lambda a, b: F.conv2d(a, b, None, stride=s, padding=p)
+        dut = lambda a, b: ops.conv2d(a, b, None, (s, s), (p, p))
+    else:
+        w = rnd(torch.randn(Ci, Co, k, k, generator=g) * 0.1)
+        ref = lambda a, b: F.conv_transpose2d(a, b, None, stride=s, padding=p)
+        dut = lambda a, b: ops.conv_transpose2d(a, b, None, (s, s), (p, p))
+    xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    yr = ref(xr, wr)
+    gy = rnd(torch.randn(yr.shape, generator=g))
+    yr.backward(gy)
+    previous = ops.set_matmul_precision("bf16")
+    try:
+        xd, wd = x.to(gpu).requires_grad_(True), w.to(gpu).requires_grad_(True)
+        y = dut(xd, wd)
+        y.backward(gy.to(gpu))
+    finally:
+        ops.set_matmul_precision(previous)
+    _close(y, yr, what="bf16 fwd")
+    _close(xd.grad, xr.grad, what="bf16 input gradient")
+    _close(wd.grad, wr.grad, what="bf16 weight gradient")
+
+
+def test_bf16_mode_rounds_operands_to_nearest_even(gpu):
+    """On general f32 operands the bf16 mode must equal an f32 convolution of the bf16-rounded operands (so its error
+    against true f32 is the operand rounding, about 2^-9 relative per product, and nothing else)."""
+    from vegans.engine import ops
+    g = torch.Generator().manual_seed(77)
+    x = torch.randn(4, 32, 12, 12, generator=g)
+    w = torch.randn(64, 32, 3, 3, generator=g) * 0.1
+    want = F.conv2d(x.bfloat16().float(), w.bfloat16().float(), None, stride=1, padding=1)
+    exact = F.conv2d(x, w, None, stride=1, padding=1)
+    previous = ops.set_matmul_precision("bf16")
+    try:
+        got = ops.conv2d(x.to(gpu), w.to(gpu), None, (1, 1), (1, 1))
+    finally:
+        ops.set_matmul_precision(previous)
+    _close(got, want, what="bf16 conv vs f32 conv of rounded operands")
+    err = float((got.cpu() - exact).abs().max() / exact.abs().max())
+    assert 1e-5 < err < 2e-2, err       # really ran in bf16, and stays within the mode's stated tolerance
+
+
 CONVT_CASES = [
     # N, Cin, Hi, Wi, Cout, k, s, p
     (4, 100, 1, 1, 64, 4, 1, 0),    # latent vector -> 4x4 (single GEMM path)
