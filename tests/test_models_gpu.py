@@ -124,6 +124,38 @@ def test_fit_matches_reference_fixture(gpu, name):
         assert biggest == float(np.float32(case.get("clip_val", 0.01)))      # bit-exact clamp bound
 
 
+@pytest.mark.parametrize("name", ["wgangp_dcgan64", "lsgan_dcgan16", "cwgangp_onehot"])
+def test_bf16_mode_tracks_the_reference_within_its_tolerance(gpu, name):
+    """bf16 mode (bf16 matrix-core operands, f32 accumulation, everything else f32) against the reference's recorded
+    fp32 run: every sub-step's losses within 2e-2 relative (floor 0.1: losses are O(0.1..1)), the tolerance stated
+    for this mode. Parameters are not compared element-wise: per-product rounding of 2^-9 is far above the 1e-4
+    statement that only holds for fp32 mode."""
+    from vegans.engine import ops
+    fx = gu.load(name)
+    case = fx["meta"]
+    nets = gu.build_nets(case)
+    torch.manual_seed(case["seed"])
+    np.random.seed(case["seed"])
+    previous = ops.set_matmul_precision("bf16")
+    try:
+        model = _build_model(case, nets)
+        record = []
+        _inject(model, [torch.from_numpy(z) for z in fx["Z"]], fx["alpha"], record)
+        _fit(model, case, fx["X"], fx["y"])
+    finally:
+        ops.set_matmul_precision(previous)
+    rows = gu.loss_rows(fx)
+    assert len(record) == len(rows)
+    worst = 0.0
+    for i, ((who, got), (_, want)) in enumerate(zip(record, rows)):
+        for k, v in want.items():
+            if k == "RealFakeRatio":
+                continue
+            _close(float(got[k]), v, 2e-2, 1e-1, "bf16 step %d %s %s" % (i, who, k))
+            worst = max(worst, abs(float(got[k]) - v) / max(abs(v), 1e-1))
+    assert worst > 1e-6, "bf16 mode did not change a single loss: the mode was not active"
+
+
 def _oracle_and_model(algo, cls, nets_fn, x_dim, z_dim, optim_kwargs, seed=3):
     from oracle.restated import OracleGAN
     case = dict(algo=algo, cls=cls, x_dim=x_dim, z_dim=z_dim, optim_kwargs=optim_kwargs, fixed_noise_size=4)
