@@ -175,7 +175,48 @@ __global__ void __launch_bounds__(256) dgrad_scatter_kernel(const float* __restr
   float acc[NP];
 #pragma unroll
   for (int k = 0; k < NP; ++k) acc[k] = 0.f;
-  if ((unsigned)ho < (unsigned)Ho && (unsigned)wo < (unsigned)Wo) {
+  // The tile's gy values come in through LDS, 32 channels at a time: 8 consecutive threads fetch the 128 contiguous
+  // bytes of one pixel (a thread reading its own pixel straight from memory touches 16 bytes of a different line per
+  // lane, and the lines are evicted before the next 16 bytes are wanted). The staging area shares `part`.
+  constexpr int CCH = 32, LDS_ = CCH + 4;
+  float* stage = part;
+  constexpr bool kStaged = 256 * LDS_ <= 256 * LDP;
+  const bool mine = (unsigned)ho < (unsigned)Ho && (unsigned)wo < (unsigned)Wo;
+  if constexpr (kStaged) {
+    // the 8 (pixel, 4-channel group) slots this thread fetches per chunk
+    long long src[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int pp = (threadIdx.x >> 3) + 32 * j;
+      const int py = pp / RW, px = pp - py * RW;
+      const int qh = h0 + py, qw = w0 + px;
+      src[j] = ((unsigned)qh < (unsigned)Ho && (unsigned)qw < (unsigned)Wo)
+                   ? ((long long)(n * Ho + qh) * Wo + qw) * Co + 4 * (threadIdx.x & 7) : -1;
+    }
+    for (int cc0 = 0; cc0 < Co; cc0 += CCH) {
+      __syncthreads();
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (src[j] >= 0 && cc0 + 4 * (int)(threadIdx.x & 7) < Co) v = *reinterpret_cast<const f32x4*>(gy + src[j] + cc0);
+        *reinterpret_cast<f32x4*>(&stage[((threadIdx.x >> 3) + 32 * j) * LDS_ + 4 * (threadIdx.x & 7)]) = v;
+      }
+      __syncthreads();
+      if (mine) {
+        const int cmax = min(CCH, Co - cc0);
+        for (int c4 = 0; c4 < cmax; c4 += 4) {
+          const f32x4 gv = *reinterpret_cast<const f32x4*>(&stage[threadIdx.x * LDS_ + c4]);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float* wc = w + (size_t)(cc0 + c4 + e) * NP;
+#pragma unroll
+            for (int k = 0; k < NP; ++k) acc[k] = fmaf(gv[e], wc[k], acc[k]);
+          }
+        }
+      }
+    }
+    __syncthreads();
+  } else if (mine) {
     const float* g = gy + ((size_t)(n * Ho + ho) * Wo + wo) * Co;
     // the next quad of channels is fetched while the current one is being used
     f32x4 gv = *reinterpret_cast<const f32x4*>(g);
