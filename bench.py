@@ -69,6 +69,20 @@ def cpu_baseline(iterations=2, warmup=1):
                       "CPU kernels" % (iterations, BATCH_PER_GPU, warmup)}
 
 
+def measured_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the committed PMC passes (profiles/round1_pmc_summary.json, written by
+    tools/pmc_summary.py from rocprofv3 FETCH_SIZE / WRITE_SIZE runs of this benchmark), or None."""
+    path = os.path.join(ROOT, "profiles", "round1_pmc_summary.json")
+    try:
+        kernels = json.load(open(path))["kernels"]
+    except (OSError, ValueError, KeyError):
+        return None
+    for name, entry in kernels.items():
+        if kernel in name:
+            return entry["hbm_bytes_per_launch"]
+    return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -206,7 +220,8 @@ def main():
             all_fl = sum(v[2] for v in summary.values())
             out["roofline"] = {
                 "bound": "mfma", "kernel": name, "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS,
-                "unit": "TFLOP/s", "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                "unit": "TFLOP/s", "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4),
+                "traffic": measured_traffic(name) if args.dtype == "fp32" else None,
                 "launches": n, "avg_launch_us": round(1e3 * ms / n, 2),
                 "ms_per_step": round(ms / ROOFLINE_STEPS, 3),
                 "timed": "HIP events around each launch, %d eager iterations after the timed region (the timed "

@@ -95,7 +95,11 @@ extern "C" int vg_conv2d_variant(int mode, const vg_conv_geom* g, char* buf, siz
   }
   const bool gemm_dgrad = g->Ho == 1 && g->Wo == 1 && g->ph == 0 && g->pw == 0 && g->H == g->kh && g->W == g->kw;
   if (mode == 1 && !gemm_dgrad && vg_thin_dgrad_applies(g)) {
-    snprintf(buf, len, "dgrad_thin_kernel<%d>", g->Ci);
+    const int taps = g->kh * g->kw;
+    if (g->Co % 4 == 0 && (taps == 9 || taps == 16 || taps == 25))
+      snprintf(buf, len, "dgrad_scatter_kernel<%d, %d>", g->Ci, taps);
+    else
+      snprintf(buf, len, "dgrad_thin_kernel<%d>", g->Ci);
     return VG_OK;
   }
   if (mode == 0) {
@@ -116,7 +120,7 @@ extern "C" int vg_conv2d_variant(int mode, const vg_conv_geom* g, char* buf, siz
   }
   const int bn = igemm_pick_bn(ncols);
   const int bm = mode == 2 ? (rows <= 64 && bn != 32 ? 64 : 128) : igemm_pick_bm(rows, (ncols + bn - 1) / bn, zdim, bn);
-  snprintf(buf, len, "igemm_kernel<%d, %d, %d, %d, %s, %d, %d>", kmode, bm, bn, igemm_waves_m(bm, bn),
-           bmc ? "true" : "false", va, vb);
+  snprintf(buf, len, "igemm_kernel<%d, %d, %d, %d, %s, %d, %d, 0>", kmode, bm, bn, igemm_waves_m(bm, bn),
+           bmc ? "true" : "false", va, vb);   // trailing 0: the f32 instance (what the un-suffixed entry points run)
   return VG_OK;
 }

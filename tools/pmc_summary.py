@@ -4,6 +4,8 @@
 (each in its own run: the TCC block cannot hold FETCH_SIZE and WRITE_SIZE together).
 
 usage: python tools/pmc_summary.py <dir pass1> <dir pass2> <dir pass3> <out.md> "<profiled command>"
+Also writes <out>.json: {kernel name: {"hbm_bytes_per_launch": ..., "launches": ...}}, which bench.py reads to report the
+dominant kernel's measured traffic next to its algorithmic work.
 
 HBM bytes follow the gfx950 reading of the counters: FETCH_SIZE and WRITE_SIZE are in KiB, and FETCH_SIZE counts a
 128-byte request of a wide (16 B per lane) coalesced read as 64 bytes, so reads = 2 * FETCH_SIZE * 1024 (an upper
@@ -13,6 +15,7 @@ MFMA flops = SQ_INSTS_VALU_MFMA_MOPS_F32 * 512.  Effective clock = GRBM_GUI_ACTI
 import collections
 import csv
 import glob
+import json
 import os
 import sys
 
@@ -50,6 +53,15 @@ def main():
         for disp, name in nx.items():
             agg[name][key] += cx[disp].get(key, 0.0)
             agg[name][key + "_calls"] += 1
+    traffic = {}
+    for name, a in agg.items():
+        if a["FETCH_SIZE_calls"] and a["WRITE_SIZE_calls"]:
+            traffic[name] = {
+                "hbm_bytes_per_launch": round(2.0 * a["FETCH_SIZE"] * 1024 / a["FETCH_SIZE_calls"] +
+                                              a["WRITE_SIZE"] * 1024 / a["WRITE_SIZE_calls"]),
+                "launches": int(a["calls"])}
+    with open(os.path.splitext(out)[0] + ".json", "w") as f:
+        json.dump({"command": cmd, "kernels": traffic}, f, indent=1, sort_keys=True)
     with open(out, "w") as f:
         f.write("# rocprofv3 --kernel-trace --pmc (3 passes) : %s\n\n" % cmd)
         f.write("Per launch averages. read = 2 x FETCH_SIZE KiB (gfx950 wide-read correction), write = WRITE_SIZE KiB, "
