@@ -8,9 +8,13 @@ namespace {
 
 constexpr int kMaxRowBlocks = 512;
 
+// A block of the partial kernel reduces a slab of rows x 64 channels (16 threads across the channels, 16 down the
+// rows): the grid is (row slabs, channel chunks), so a short, wide activation (4096 x 512) still fills the chip.
+constexpr int kChunkChannels = 64;
+
 inline int row_blocks(int M) {
-  // at least 64 rows per block; at most kMaxRowBlocks blocks
-  int nb = (M + 63) / 64;
+  // at least 128 rows per block (8 per thread); at most kMaxRowBlocks blocks
+  int nb = (M + 127) / 128;
   if (nb > kMaxRowBlocks) nb = kMaxRowBlocks;
   if (nb < 1) nb = 1;
   return nb;
@@ -21,21 +25,24 @@ template <int NV, int VEC, class F>
 __global__ void __launch_bounds__(256) colreduce_partial(F f, int M, int C, int rows_per_block, float* partial) {
   __shared__ float red[NV * VEC * 256];
   const int CG = C / VEC;
-  const int TX = CG < 256 ? CG : 256;
+  constexpr int CGB = kChunkChannels / VEC;          // channel groups per block
+  const int cg_lo = blockIdx.y * CGB, cg_hi = min(cg_lo + CGB, CG);
+  const int span = cg_hi - cg_lo;
+  const int TX = span < 256 ? span : 256;
   const int TY = 256 / TX;
   const int tid = threadIdx.x;
   const int tx = tid % TX, ty = tid / TX;
   const int nblk = gridDim.x;
   const int row0 = blockIdx.x * rows_per_block;
   const int row1 = min(row0 + rows_per_block, M);
-  for (int cg0 = 0; cg0 < CG; cg0 += TX) {
+  for (int cg0 = cg_lo; cg0 < cg_hi; cg0 += TX) {
     const int cg = cg0 + tx;
     float acc[NV][VEC];
 #pragma unroll
     for (int v = 0; v < NV; ++v)
 #pragma unroll
       for (int e = 0; e < VEC; ++e) acc[v][e] = 0.f;
-    if (ty < TY && cg < CG) {
+    if (ty < TY && cg < cg_hi) {
 #pragma unroll 4
       for (int row = row0 + ty; row < row1; row += TY) f.template eval<VEC>((size_t)row * C + (size_t)cg * VEC, cg * VEC, acc);
     }
@@ -44,7 +51,7 @@ __global__ void __launch_bounds__(256) colreduce_partial(F f, int M, int C, int 
 #pragma unroll
       for (int e = 0; e < VEC; ++e) red[(v * VEC + e) * 256 + tid] = acc[v][e];
     __syncthreads();
-    if (ty == 0 && cg < CG) {
+    if (ty == 0 && cg < cg_hi) {
 #pragma unroll
       for (int v = 0; v < NV; ++v)
 #pragma unroll
@@ -109,10 +116,11 @@ int run_colreduce_with(const char* who, F f, int M, int C, bool vec_ok, E epilog
   if (!ws || ws_bytes < need) return vg_fail(VG_ERR_WORKSPACE, "%s: workspace of %zu bytes required, got %zu", who, need, ws_bytes);
   const int rpb = (M + nb - 1) / nb;
   float* partial = (float*)ws;
+  const dim3 grid(nb, (C + kChunkChannels - 1) / kChunkChannels);
   if (vec_ok && C % 4 == 0)
-    hipLaunchKernelGGL((colreduce_partial<NV, 4, F>), dim3(nb), dim3(256), 0, st, f, M, C, rpb, partial);
+    hipLaunchKernelGGL((colreduce_partial<NV, 4, F>), grid, dim3(256), 0, st, f, M, C, rpb, partial);
   else
-    hipLaunchKernelGGL((colreduce_partial<NV, 1, F>), dim3(nb), dim3(256), 0, st, f, M, C, rpb, partial);
+    hipLaunchKernelGGL((colreduce_partial<NV, 1, F>), grid, dim3(256), 0, st, f, M, C, rpb, partial);
   VG_CHECK_LAUNCH(who);
   hipLaunchKernelGGL((colreduce_final<NV, E>), dim3((C + 15) / 16), dim3(256), 0, st, (const float*)partial, nb, C, epilogue);
   VG_CHECK_LAUNCH(who);
