@@ -33,6 +33,8 @@ CONV_CASES = [
     (3, 1, 12, 12, 12, 5, 2, 2),     # Ci=1, 5x5 stride 2
     (1, 2, 140, 150, 4, 4, 2, 1),    # Ci=2, gradient image larger than one tile in both dimensions
     (2, 4, 37, 21, 8, 4, 2, 1),      # Ci=4, several row tiles, odd sizes
+    (8, 3, 64, 64, 16, 4, 2, 1),     # image stem at full resolution: per-pixel stem kernel forward
+    (4, 1, 40, 40, 8, 3, 1, 1),      # stem kernel, 3x3 stride 1, Ci=1
 ]
 
 
