@@ -36,9 +36,9 @@ extern "C" int vg_conv2d_dgrad_prec(const vg_conv_geom* g, const float* gy, cons
   p.M = g->N * Hc * Wc;
   p.fast_div = p.M < (1 << 22) ? 1 : 0;
   p.Ktot = 0;  // per class, derived in the kernel
-  const int bn = igemm_pick_bn(p.Ncols);
+  const int bn = igemm_pick_bn(p.Ncols, precision);
   p.ntiles = (p.Ncols + bn - 1) / bn;
-  const int bm = igemm_pick_bm(p.M, p.ntiles, g->sh * g->sw, bn);
+  const int bm = igemm_pick_bm(p.M, p.ntiles, g->sh * g->sw, bn, precision);
   p.mtiles = (p.M + bm - 1) / bm;
   const int va = (g->Co % 4 == 0 && vg_aligned16(gy)) ? 4 : 1;
   const int vb = (g->Ci % 4 == 0 && vg_aligned16(w)) ? 4 : 1;

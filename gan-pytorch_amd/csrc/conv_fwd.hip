@@ -45,9 +45,9 @@ extern "C" int vg_conv2d_fwd_prec(const vg_conv_geom* g, const float* x, const f
   p.Ncols = g->Co;
   p.Ktot = g->kh * g->kw * g->Ci;
   p.bias_mod = g->Co;
-  const int bn = igemm_pick_bn(p.Ncols);
+  const int bn = igemm_pick_bn(p.Ncols, precision);
   p.ntiles = (p.Ncols + bn - 1) / bn;
-  const int bm = igemm_pick_bm(p.M, p.ntiles, 1, bn);
+  const int bm = igemm_pick_bm(p.M, p.ntiles, 1, bn, precision);
   p.mtiles = (p.M + bm - 1) / bm;
   const int va = (g->Ci % 4 == 0 && vg_aligned16(x)) ? 4 : 1;
   const int vb = (p.Ktot % 4 == 0 && vg_aligned16(w)) ? 4 : 1;
@@ -69,9 +69,9 @@ int vg_gemm_kn(const float* A, const float* B, const float* bias, int bias_mod, 
   p.Ho = 1; p.Wo = 1; p.sh = 1; p.sw = 1; p.ph = 0; p.pw = 0;
   p.M = M; p.Ncols = Ncols; p.Ktot = K; p.bias_mod = bias_mod;
   p.fast_div = p.M < (1 << 22) ? 1 : 0;
-  const int bn = igemm_pick_bn(Ncols);
+  const int bn = igemm_pick_bn(Ncols, precision);
   p.ntiles = (Ncols + bn - 1) / bn;
-  const int bm = igemm_pick_bm(M, p.ntiles, 1, bn);
+  const int bm = igemm_pick_bm(M, p.ntiles, 1, bn, precision);
   p.mtiles = (M + bm - 1) / bm;
   const int va = (K % 4 == 0 && vg_aligned16(A)) ? 4 : 1;
   const int vb = (Ncols % 4 == 0 && vg_aligned16(B)) ? 4 : 1;

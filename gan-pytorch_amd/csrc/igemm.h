@@ -669,14 +669,19 @@ static inline int igemm_launch(const IgemmParams& p, int bm, int bn, int va, int
 static inline int igemm_waves_m(int bm, int bn) { return (bm == 128 && bn == 32) ? 4 : 2; }
 
 // Rows per tile: 128 unless that leaves the 256 CUs with at most one block each and a 64-row tile exists for this BN
-// (measured on the DCGAN layers: 256 blocks of 128 rows reach 99-110 TFLOP/s, 512 blocks of 64 rows 102-117).
-static inline int igemm_pick_bm(long long rows, int ntiles, int zdim, int bn) {
+// (measured on the DCGAN layers: 256 blocks of 128 rows reach 99-110 TFLOP/s, 512 blocks of 64 rows 102-117). The
+// bf16 kernels were measured with smaller tiles / more blocks as well (64x64 up to 2000 blocks): no gain, same rule.
+static inline int igemm_pick_bm(long long rows, int ntiles, int zdim, int bn, int prec = PREC_F32) {
+  (void)prec;
   if (bn == 32 || rows <= 64) return rows <= 64 && bn != 32 ? 64 : 128;
   const long long blocks128 = ((rows + 127) / 128) * ntiles * zdim;
-  return blocks128 < 300 ? 64 : 128;   // up to one 128-row block per CU: halve the tiles, two blocks per CU
+  return blocks128 < 300 ? 64 : 128;
 }
 
-static inline int igemm_pick_bn(int ncols) { return ncols > 64 ? 128 : (ncols > 32 ? 64 : 32); }
+static inline int igemm_pick_bn(int ncols, int prec = PREC_F32) {
+  (void)prec;
+  return ncols > 64 ? 128 : (ncols > 32 ? 64 : 32);
+}
 
 // shared by the conv translation units
 int vg_check_geom(const vg_conv_geom* g, const char* who);
