@@ -63,12 +63,14 @@ struct IgemmParams {
 #define IGEMM_BK 32
 #define IGEMM_LDK 36
 
-template <int MODE, int BM, int BN, int WAVES_M, bool B_MC, int VA, int VB, int PREC = PREC_F32>
-__global__ void __launch_bounds__(256) igemm_kernel(const IgemmParams p) {
+template <int MODE, int BM, int BN, int WAVES_M, bool B_MC, int VA, int VB, int PREC = PREC_F32, int NW = 4>
+__global__ void __launch_bounds__(NW * 64) igemm_kernel(const IgemmParams p) {
+  constexpr int NT = NW * 64;      // threads per block
+  constexpr int RPT = NT / 8;      // rows one pass of the [row][k] loaders covers (8 threads x 16 bytes span the 32 k)
   constexpr int BK = IGEMM_BK, LDK = IGEMM_LDK;
   constexpr bool BF = PREC == PREC_BF16;
   constexpr int LDB = 40;   // bf16 elements per row of a [row][k] bf16 tile
-  constexpr int WAVES_N = 4 / WAVES_M;
+  constexpr int WAVES_N = NW / WAVES_M;
   constexpr int TM = BM / (WAVES_M * 32), TN = BN / (WAVES_N * 32);
   constexpr bool A_MC = (MODE == MODE_WGRAD);
   constexpr bool B_IS_MC = B_MC || (MODE != MODE_FWD);
@@ -126,8 +128,8 @@ __global__ void __launch_bounds__(256) igemm_kernel(const IgemmParams p) {
   const int nk = (kend - kbeg + BK - 1) / BK;
 
   // ---- A loader state -----------------------------------------------------------------------
-  constexpr int RA = BM / 32;  // rows per thread, [row][k] layout
-  constexpr int TPRA = BM / 4, RPA = 256 / TPRA, PA = BK / RPA;  // [k][row] layout
+  constexpr int RA = BM / RPT;  // rows per thread, [row][k] layout
+  constexpr int TPRA = BM / 4, RPA = NT / TPRA, PA = BK / RPA;  // [k][row] layout
   int a_img[A_MC ? 1 : RA], a_h[A_MC ? 1 : RA], a_w[A_MC ? 1 : RA];
   // row index -> (image, y, x): plane = pixels per image, roww = pixels per image row, of the tensor the rows walk
   const bool fast = p.fast_div != 0;
@@ -137,7 +139,7 @@ __global__ void __launch_bounds__(256) igemm_kernel(const IgemmParams p) {
   if constexpr (!A_MC) {
 #pragma unroll
     for (int i = 0; i < RA; ++i) {
-      const int m = m0 + (tid >> 3) + 32 * i;
+      const int m = m0 + (tid >> 3) + RPT * i;
       a_img[i] = 0;
       a_w[i] = 0;
       a_h[i] = -(1 << 28);
@@ -160,8 +162,8 @@ __global__ void __launch_bounds__(256) igemm_kernel(const IgemmParams p) {
   }
 
   // ---- B loader state -----------------------------------------------------------------------
-  constexpr int RB = BN / 32;
-  constexpr int TPRB = BN / 4, RPB = 256 / TPRB, PB = BK / RPB;
+  constexpr int RB = BN / RPT;
+  constexpr int TPRB = BN / 4, RPB = NT / TPRB, PB = BK / RPB;
   static_assert(!BF || ((!A_MC || PA % 2 == 0) && (!B_IS_MC || PB % 2 == 0)), "bf16 [k][row] tiles pair adjacent k rows");
   // k row (inside a 32-deep step) of the i-th 16-byte load of a [k][row] tile; in bf16 mode loads 2j and 2j+1 of a
   // thread are the two rows of one packed pair
@@ -313,7 +315,7 @@ __global__ void __launch_bounds__(256) igemm_kernel(const IgemmParams p) {
       const int k4 = kb + 4 * (tid & 7);
 #pragma unroll
       for (int i = 0; i < RB; ++i) {
-        const int n = n0 + (tid >> 3) + 32 * i;
+        const int n = n0 + (tid >> 3) + RPT * i;
         if constexpr (VB == 4) {
           rb[i] = ld4(p.B, (size_t)n * Ktot + k4, n < p.Ncols && k4 < kend);
         } else {
@@ -423,7 +425,7 @@ __global__ void __launch_bounds__(256) igemm_kernel(const IgemmParams p) {
       if constexpr (!A_MC) {
 #pragma unroll
         for (int i = 0; i < RA; ++i)
-          *reinterpret_cast<f32x4*>(&As[((tid >> 3) + 32 * i) * LDK + 4 * (tid & 7)]) = ra[i];
+          *reinterpret_cast<f32x4*>(&As[((tid >> 3) + RPT * i) * LDK + 4 * (tid & 7)]) = ra[i];
       } else {
 #pragma unroll
         for (int i = 0; i < PA; ++i)
@@ -432,7 +434,7 @@ __global__ void __launch_bounds__(256) igemm_kernel(const IgemmParams p) {
       if constexpr (!B_IS_MC) {
 #pragma unroll
         for (int i = 0; i < RB; ++i)
-          *reinterpret_cast<f32x4*>(&Bs[((tid >> 3) + 32 * i) * LDK + 4 * (tid & 7)]) = rb[i];
+          *reinterpret_cast<f32x4*>(&Bs[((tid >> 3) + RPT * i) * LDK + 4 * (tid & 7)]) = rb[i];
       } else {
 #pragma unroll
         for (int i = 0; i < PB; ++i)
@@ -447,7 +449,7 @@ __global__ void __launch_bounds__(256) igemm_kernel(const IgemmParams p) {
         __bf16* Ah = reinterpret_cast<__bf16*>(As);
 #pragma unroll
         for (int i = 0; i < RA; ++i)
-          *reinterpret_cast<bf16x4*>(&Ah[((tid >> 3) + 32 * i) * LDB + 4 * (tid & 7)]) = __builtin_convertvector(ra[i], bf16x4);
+          *reinterpret_cast<bf16x4*>(&Ah[((tid >> 3) + RPT * i) * LDB + 4 * (tid & 7)]) = __builtin_convertvector(ra[i], bf16x4);
       } else {
         unsigned int* Au = reinterpret_cast<unsigned int*>(As);
 #pragma unroll
@@ -461,7 +463,7 @@ __global__ void __launch_bounds__(256) igemm_kernel(const IgemmParams p) {
         __bf16* Bh = reinterpret_cast<__bf16*>(Bs);
 #pragma unroll
         for (int i = 0; i < RB; ++i)
-          *reinterpret_cast<bf16x4*>(&Bh[((tid >> 3) + 32 * i) * LDB + 4 * (tid & 7)]) = __builtin_convertvector(rb[i], bf16x4);
+          *reinterpret_cast<bf16x4*>(&Bh[((tid >> 3) + RPT * i) * LDB + 4 * (tid & 7)]) = __builtin_convertvector(rb[i], bf16x4);
       } else {
         unsigned int* Bu = reinterpret_cast<unsigned int*>(Bs);
 #pragma unroll
@@ -636,6 +638,12 @@ __global__ void __launch_bounds__(256) igemm_kernel(const IgemmParams p) {
   }
 }
 
+// Waves per block of the variant that serves (bm, bn, va, vb, prec).
+static inline int igemm_waves(int bm, int bn, int va, int vb, int prec) {
+  const bool large = (bm == 128 && bn == 128) || (bm == 128 && bn == 64) || (bm == 64 && bn == 128);
+  return prec == PREC_F32 && va == 4 && vb == 4 && large ? 8 : 4;
+}
+
 // Launch one (BM, BN, VA, VB) variant chosen at run time; the wave arrangement follows the tile. prec = PREC_BF16 is
 // served for 16-byte-vector operands on the tiles that keep [k][row] pairs whole, anything else runs in f32.
 template <int MODE, bool B_MC>
@@ -645,6 +653,14 @@ static inline int igemm_launch(const IgemmParams& p, int bm, int bn, int va, int
   if (bm == BM_ && bn == BN_ && va == VA_ && vb == VB_) {                                                  \
     hipLaunchKernelGGL((igemm_kernel<MODE, BM_, BN_, WM_, B_MC, VA_, VB_, P_>), grid, dim3(256), 0, st, p); \
     return 0;                                                                                              \
+  }
+  // f32, 16-byte-vector operands: eight waves per block on the three large tiles (half the accumulators per wave, so
+  // two blocks bring four waves to every SIMD instead of two; measured +2..10 % on the DCGAN layers)
+  if (igemm_waves(bm, bn, va, vb, prec) == 8) {
+    if (bm == 128 && bn == 128) hipLaunchKernelGGL((igemm_kernel<MODE, 128, 128, 2, B_MC, 4, 4, PREC_F32, 8>), grid, dim3(512), 0, st, p);
+    else if (bm == 128) hipLaunchKernelGGL((igemm_kernel<MODE, 128, 64, 4, B_MC, 4, 4, PREC_F32, 8>), grid, dim3(512), 0, st, p);
+    else hipLaunchKernelGGL((igemm_kernel<MODE, 64, 128, 2, B_MC, 4, 4, PREC_F32, 8>), grid, dim3(512), 0, st, p);
+    return 0;
   }
   if (prec == PREC_BF16 && va == 4 && vb == 4) {
     IGEMM_CASE_P(128, 128, 2, 4, 4, PREC_BF16)
@@ -666,7 +682,11 @@ static inline int igemm_launch(const IgemmParams& p, int bm, int bn, int va, int
   return -1;
 }
 
-static inline int igemm_waves_m(int bm, int bn) { return (bm == 128 && bn == 32) ? 4 : 2; }
+// WAVES_M template argument of the variant (for naming the instance a launch ran)
+static inline int igemm_waves_m(int bm, int bn, int nw = 4) {
+  if (nw == 8) return (bm == 128 && bn == 64) ? 4 : 2;
+  return (bm == 128 && bn == 32) ? 4 : 2;
+}
 
 // Rows per tile: 128 unless that leaves the 256 CUs with at most one block each and a 64-row tile exists for this BN
 // (measured on the DCGAN layers: 256 blocks of 128 rows reach 99-110 TFLOP/s, 512 blocks of 64 rows 102-117). The
