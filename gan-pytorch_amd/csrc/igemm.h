@@ -662,8 +662,12 @@ static inline int igemm_launch(const IgemmParams& p, int bm, int bn, int va, int
     else hipLaunchKernelGGL((igemm_kernel<MODE, 64, 128, 2, B_MC, 4, 4, PREC_F32, 8>), grid, dim3(512), 0, st, p);
     return 0;
   }
+  if (prec == PREC_BF16 && va == 4 && vb == 4 && bm == 128 && bn == 128) {   // eight waves here too (the other tiles
+    // would leave a thread with a single row of a packed [k][row] pair)
+    hipLaunchKernelGGL((igemm_kernel<MODE, 128, 128, 2, B_MC, 4, 4, PREC_BF16, 8>), grid, dim3(512), 0, st, p);
+    return 0;
+  }
   if (prec == PREC_BF16 && va == 4 && vb == 4) {
-    IGEMM_CASE_P(128, 128, 2, 4, 4, PREC_BF16)
     IGEMM_CASE_P(128, 64, 2, 4, 4, PREC_BF16)
     IGEMM_CASE_P(64, 128, 2, 4, 4, PREC_BF16)
     IGEMM_CASE_P(64, 64, 2, 4, 4, PREC_BF16)
