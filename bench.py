@@ -70,12 +70,13 @@ def cpu_baseline(iterations=2, warmup=1):
 
 
 def measured_traffic(kernel):
-    """HBM bytes per launch of `kernel` from the committed PMC passes (profiles/round1_pmc_summary.json, written by
+    """HBM bytes per launch of `kernel` from the newest committed PMC summary (profiles/*_pmc_summary.json, written by
     tools/pmc_summary.py from rocprofv3 FETCH_SIZE / WRITE_SIZE runs of this benchmark), or None."""
-    path = os.path.join(ROOT, "profiles", "round1_pmc_summary.json")
+    import glob
+    found = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_summary.json")))
     try:
-        kernels = json.load(open(path))["kernels"]
-    except (OSError, ValueError, KeyError):
+        kernels = json.load(open(found[-1]))["kernels"]
+    except (IndexError, OSError, ValueError, KeyError):
         return None
     for name, entry in kernels.items():
         if kernel in name:
