@@ -242,10 +242,45 @@ class OracleGAN:
                 p.data.clamp_(-self.clip_val, self.clip_val)
         return {k: float(v.detach()) for k, v in losses.items()}
 
-    def fit(self, X_train, y_train=None, epochs=1, batch_size=32, steps=None, latents=None, alphas=None):
+    def sub_step_sharded(self, who, X, Z, y=None, alpha=None, shards=2):
+        """The same sub-step as nn.DataParallel runs it over `shards` devices (utils/networks.py:39-41): the batch is
+        cut into contiguous dim-0 chunks (torch.chunk), every chunk goes through the networks on its own, so BatchNorm
+        uses per-chunk statistics; the loss is the mean over the whole batch, i.e. the chunk means weighted by
+        rows/batch; gradients add up; only the first replica's BatchNorm buffers survive (the other replicas are
+        thrown away after the forward pass). Emulated here on one module by running the chunks one after the other and
+        restoring, at the end, the buffers as they were after the first chunk."""
+        rows = len(X)
+        bounds = []
+        start = 0
+        for piece in torch.chunk(torch.arange(rows), shards):
+            bounds.append((start, start + len(piece)))
+            start += len(piece)
+        self.optimizers[who].zero_grad()
+        totals, first_buffers = {}, None
+        for lo, hi in bounds:
+            part = self.losses(who, X[lo:hi], Z[lo:hi], None if y is None else y[lo:hi],
+                               None if alpha is None else alpha[lo:hi])
+            weight = (hi - lo) / float(rows)
+            (part[who] * weight).backward(retain_graph=True)
+            for k, v in part.items():
+                totals[k] = totals.get(k, 0.0) + weight * float(v.detach())
+            if first_buffers is None:
+                first_buffers = {name: {k: b.detach().clone() for k, b in net.named_buffers()}
+                                 for name, net in self.nets.items()}
+        for name, net in self.nets.items():
+            for k, b in net.named_buffers():
+                b.data.copy_(first_buffers[name][k])
+        self.optimizers[who].step()
+        if self.algo == "wgan" and who == "Adversariat":
+            for p in self.nets["Adversariat"].parameters():
+                p.data.clamp_(-self.clip_val, self.clip_val)
+        return totals
+
+    def fit(self, X_train, y_train=None, epochs=1, batch_size=32, steps=None, latents=None, alphas=None, shards=1):
         """The hot loop of AbstractGenerativeModel.py:312-327 / AbstractConditionalGenerativeModel.py:125-141
         (logging off). `latents` / `alphas` are optional iterators of injected Z batches / alpha arrays; when
         absent Z comes from torch.randn and alpha from numpy's global generator in the reference's order.
+        `shards` > 1 runs every sub-step the way nn.DataParallel would over that many devices (sub_step_sharded).
         Returns the list of per-sub-step loss dicts."""
         plan = {name: 1 for name in self.nets}
         plan.update(steps or {})
@@ -261,7 +296,10 @@ class OracleGAN:
                         alpha = None
                         if self.algo == "wgangp" and name == "Adversariat" and alphas is not None:
                             alpha = next(alphas)
-                        history.append((name, self.sub_step(name, X, Z, y, alpha)))
+                        if shards > 1:
+                            history.append((name, self.sub_step_sharded(name, X, Z, y, alpha, shards)))
+                        else:
+                            history.append((name, self.sub_step(name, X, Z, y, alpha)))
         self._set_mode(False)
         return history
 

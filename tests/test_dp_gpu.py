@@ -1,7 +1,8 @@
-"""Data-parallel path on the GPU: two ranks (both on cuda:0, gloo transport, since one box has one GPU) train a
-BatchNorm-free WGAN-GP on a global batch sharded by rows; the result must equal a single-process run on the whole
-batch (the per-rank means weighted by rows/global_rows sum to the global mean), and both ranks must end with
-identical weights.  The run is long enough for the iteration to be captured and replayed as HIP graphs on both
+"""Data-parallel path on the GPU: two ranks (both on cuda:0, gloo transport, since one box has one GPU).
+1. A BatchNorm-free WGAN-GP on a global batch sharded by rows must equal a single-process run on the whole batch (the
+   per-rank means weighted by rows/global_rows sum to the global mean), and both ranks must end with identical weights.
+2. A BatchNorm DCGAN must equal the CPU oracle's emulation of nn.DataParallel over two devices (the reference's
+   multi-GPU path, utils/networks.py:39-41): per-shard batch statistics, summed gradients, rank 0's running statistics.  The run is long enough for the iteration to be captured and replayed as HIP graphs on both
 sides."""
 import os
 import subprocess
@@ -63,6 +64,49 @@ same = all(torch.equal(both[0], b) for b in both)
 print("rank %%d worst_rel %%.3e identical_across_ranks %%s" %% (rank, worst, same))
 assert same, "ranks diverged"
 assert worst < 2e-4, worst
+
+# ---- BatchNorm networks against the oracle's two-device emulation ------------------------------------------------
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import copy
+import golden_util as gu
+from oracle.restated import OracleGAN
+
+def bn_nets():
+    return (cfg.seeded_init(cfg.dcgan_generator(nz=16, ngf=8, nc=3, size=16), 1, 0.08),
+            cfg.seeded_init(cfg.dcgan_critic(ndf=8, nc=3, size=16), 2, 0.08))
+
+okw = {"Generator": {"lr": 2e-4}, "Adversariat": {"lr": 1e-4}}
+iters, B = 6, 8
+Xb = cfg.synthetic_images(B * iters, (3, 16, 16), seed=5)
+zg = torch.Generator().manual_seed(9)
+Zs = [torch.randn(B, 16, 1, 1, generator=zg) for _ in range(iters)]
+np.random.seed(23)
+As = [np.random.random((B, 1, 1, 1)) for _ in range(iters)]
+torch.manual_seed(3); np.random.seed(3)
+Go, Do = bn_nets()
+oracle = OracleGAN("wgangp", Go, Do, (3, 16, 16), (16, 1, 1), optim_kwargs=copy.deepcopy(okw), fixed_noise_size=4)
+hist = oracle.fit(Xb, None, epochs=1, batch_size=B, latents=[z.clone() for z in Zs], alphas=As, shards=world)
+torch.manual_seed(3); np.random.seed(3)
+Gm, Dm = bn_nets()
+with contextlib.redirect_stdout(io.StringIO()):
+    mb = gan.WassersteinGANGP(Gm, Dm, x_dim=(3, 16, 16), z_dim=(16, 1, 1), folder=None, fixed_noise_size=4, ngpu=world,
+                              optim_kwargs=copy.deepcopy(okw))
+zi = iter(Zs)
+mb.sample = lambda n: next(zi)[:n].to("cuda").requires_grad_(True)
+np.random.seed(23)
+with contextlib.redirect_stdout(io.StringIO()):
+    mb.fit(Xb, epochs=1, batch_size=B, print_every=None, save_losses_every=None, enable_tensorboard=False)
+problems = []
+for name, net_o in oracle.nets.items():
+    want = {k: v.detach().numpy() for k, v in net_o.state_dict().items()}
+    network = mb.neural_nets[name].network
+    got = network.state_dict()
+    if rank != 0:      # running statistics are the first replica's in the reference; other ranks keep their own shard's
+        want = {k: v for k, v in want.items() if "running_" not in k}
+        got = {k: v for k, v in got.items() if "running_" not in k}
+    problems += gu.compare_network(got, want, network, 1e-4, 2e-2, name)
+print("rank %%d batch-norm data parallel vs two-device oracle: %%d problems" %% (rank, len(problems)))
+assert not problems, "\n".join(problems)
 dist.barrier(); dist.destroy_process_group()
 print("rank", rank, "ok")
 '''

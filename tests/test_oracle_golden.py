@@ -67,3 +67,40 @@ def test_input_dim_and_wasserstein():
     assert input_dim([3, 8, 8], [3, 8, 8]) == [6, 8, 8]
     p = torch.tensor([[1.0], [3.0]])
     assert float(wasserstein(p, True)) == -2.0 and float(wasserstein(p, False)) == 2.0
+
+
+def test_two_device_emulation_equals_single_device_without_batch_norm():
+    """The oracle's nn.DataParallel emulation (sub_step_sharded) must be the plain sub-step when no layer couples the
+    rows of a batch: chunk means weighted by rows/batch are the batch mean. (With BatchNorm it differs by design:
+    per-chunk statistics.) Uneven chunks included."""
+    import copy
+
+    import numpy as np
+    import torch
+    from torch import nn
+
+    import bench_configs as cfg
+    from oracle.restated import OracleGAN
+
+    def nets():
+        G = cfg.seeded_init(cfg.dcgan_generator(nz=8, ngf=4, nc=3, size=16), 1, 0.1)
+        G = nn.Sequential(*[m for m in G if not isinstance(m, nn.BatchNorm2d)])
+        D = cfg.seeded_init(cfg.dcgan_critic(ndf=4, nc=3, size=16, batch_norm=False), 2, 0.1)
+        return G, D
+
+    X = cfg.synthetic_images(14, (3, 16, 16), seed=1)          # batches of 7: chunks of 4 and 3 rows
+    Z = [torch.randn(7, 8, 1, 1, generator=torch.Generator().manual_seed(i)) for i in range(2)]
+    A = [np.random.default_rng(i).random((7, 1, 1, 1)) for i in range(2)]
+    finals = []
+    for shards in (1, 2):
+        torch.manual_seed(0)
+        G, D = nets()
+        o = OracleGAN("wgangp", G, D, (3, 16, 16), (8, 1, 1), fixed_noise_size=2)
+        hist = o.fit(X, None, epochs=1, batch_size=7, latents=copy.deepcopy(Z), alphas=A, shards=shards)
+        finals.append((hist, [p.detach().clone() for net in (G, D) for p in net.parameters()]))
+    for (_, a), (_, b) in zip(finals[0][0], finals[1][0]):
+        for k in a:
+            if k != "RealFakeRatio":
+                assert abs(a[k] - b[k]) <= 1e-5 * max(abs(a[k]), 1e-1), (k, a[k], b[k])
+    for a, b in zip(finals[0][1], finals[1][1]):
+        assert float((a - b).abs().max()) <= 2e-3 * max(float(a.abs().max()), 1e-3)
