@@ -107,17 +107,12 @@ __global__ void __launch_bounds__(256) rmsprop_multi_kernel(RmspropMulti t, vg_r
   }
 }
 
+// one VEC-wide element group i of one tensor
 template <int VEC>
-__global__ void __launch_bounds__(256) adam_kernel(float* __restrict__ param, const float* __restrict__ grad,
-                                                   float* __restrict__ ea, float* __restrict__ eas, float* __restrict__ mx,
-                                                   size_t nvec, vg_adam_cfg c) {
-  const size_t stride = (size_t)gridDim.x * blockDim.x;
-  const bool do_clamp = c.clamp_lo <= c.clamp_hi;
-  const float w1 = 1.f - c.beta1;
-  // step-dependent scalars: by value, or (replayed graphs) from two floats the host refreshes before every launch
-  const float step_size = c.step_scalars ? c.step_scalars[0] : c.step_size;
-  const float bc2_sqrt = c.step_scalars ? c.step_scalars[1] : c.bias_correction2_sqrt;
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += stride) {
+__device__ __forceinline__ void adam_update(float* __restrict__ param, const float* __restrict__ grad,
+                                            float* __restrict__ ea, float* __restrict__ eas, float* __restrict__ mx,
+                                            size_t i, const vg_adam_cfg& c, bool do_clamp, float w1, float step_size,
+                                            float bc2_sqrt) {
     float p[VEC], g[VEC], m[VEC], v[VEC], x[VEC];
     if constexpr (VEC == 4) {
       const f32x4 pv = reinterpret_cast<f32x4*>(param)[i], gv = reinterpret_cast<const f32x4*>(grad)[i],
@@ -161,6 +156,49 @@ __global__ void __launch_bounds__(256) adam_kernel(float* __restrict__ param, co
       param[i] = p[0]; ea[i] = m[0]; eas[i] = v[0];
       if (mx) mx[i] = x[0];
     }
+}
+
+template <int VEC>
+__global__ void __launch_bounds__(256) adam_kernel(float* __restrict__ param, const float* __restrict__ grad,
+                                                   float* __restrict__ ea, float* __restrict__ eas, float* __restrict__ mx,
+                                                   size_t nvec, vg_adam_cfg c) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  const bool do_clamp = c.clamp_lo <= c.clamp_hi;
+  const float w1 = 1.f - c.beta1;
+  // step-dependent scalars: by value, or (replayed graphs) from two floats the host refreshes before every launch
+  const float step_size = c.step_scalars ? c.step_scalars[0] : c.step_size;
+  const float bc2_sqrt = c.step_scalars ? c.step_scalars[1] : c.bias_correction2_sqrt;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += stride)
+    adam_update<VEC>(param, grad, ea, eas, mx, i, c, do_clamp, w1, step_size, bc2_sqrt);
+}
+
+struct AdamMulti {
+  float* param[kMultiMax];
+  const float* grad[kMultiMax];
+  float* ea[kMultiMax];
+  float* eas[kMultiMax];
+  float* mx[kMultiMax];
+  unsigned long long n[kMultiMax];
+  int first_block[kMultiMax + 1];
+  int vec[kMultiMax];
+  int count;
+};
+
+__global__ void __launch_bounds__(256) adam_multi_kernel(AdamMulti t, vg_adam_cfg c) {
+  int k = 0;
+  while (k + 1 < t.count && (int)blockIdx.x >= t.first_block[k + 1]) ++k;    // block-uniform
+  const size_t e0 = (size_t)((int)blockIdx.x - t.first_block[k]) * kMultiChunk;
+  const size_t e1 = e0 + kMultiChunk < t.n[k] ? e0 + kMultiChunk : (size_t)t.n[k];
+  const bool do_clamp = c.clamp_lo <= c.clamp_hi;
+  const float w1 = 1.f - c.beta1;
+  const float step_size = c.step_scalars ? c.step_scalars[0] : c.step_size;
+  const float bc2_sqrt = c.step_scalars ? c.step_scalars[1] : c.bias_correction2_sqrt;
+  if (t.vec[k]) {
+    for (size_t i = e0 / 4 + threadIdx.x; i < e1 / 4; i += 256)
+      adam_update<4>(t.param[k], t.grad[k], t.ea[k], t.eas[k], t.mx[k], i, c, do_clamp, w1, step_size, bc2_sqrt);
+  } else {
+    for (size_t i = e0 + threadIdx.x; i < e1; i += 256)
+      adam_update<1>(t.param[k], t.grad[k], t.ea[k], t.eas[k], t.mx[k], i, c, do_clamp, w1, step_size, bc2_sqrt);
   }
 }
 
@@ -258,6 +296,38 @@ extern "C" int vg_adam_step(float* param, const float* grad, float* exp_avg, flo
     hipLaunchKernelGGL((adam_kernel<1>), dim3(vg_stream_grid(n, 256)), dim3(256), 0, st, param, grad, exp_avg, exp_avg_sq, mx,
                        n, *cfg);
   VG_CHECK_LAUNCH("vg_adam_step");
+  return VG_OK;
+}
+
+extern "C" int vg_adam_step_multi(int count, float* const* params, const float* const* grads, float* const* exp_avgs,
+                                  float* const* exp_avg_sqs, float* const* max_exp_avg_sqs, const size_t* n,
+                                  const vg_adam_cfg* cfg, void* stream) {
+  VG_REQUIRE(count > 0 && params && grads && exp_avgs && exp_avg_sqs && n && cfg, "vg_adam_step_multi: bad arguments");
+  VG_REQUIRE(!cfg->amsgrad || max_exp_avg_sqs, "vg_adam_step_multi: amsgrad needs max_exp_avg_sq buffers");
+  for (int base = 0; base < count; base += kMultiMax) {
+    AdamMulti t;
+    t.count = count - base < kMultiMax ? count - base : kMultiMax;
+    int blocks = 0;
+    for (int k = 0; k < t.count; ++k) {
+      const int j = base + k;
+      VG_REQUIRE(params[j] && grads[j] && exp_avgs[j] && exp_avg_sqs[j] && n[j] > 0,
+                 "vg_adam_step_multi: null tensor or empty tensor");
+      t.param[k] = params[j];
+      t.grad[k] = grads[j];
+      t.ea[k] = exp_avgs[j];
+      t.eas[k] = exp_avg_sqs[j];
+      t.mx[k] = cfg->amsgrad ? max_exp_avg_sqs[j] : nullptr;
+      VG_REQUIRE(!cfg->amsgrad || t.mx[k], "vg_adam_step_multi: missing max_exp_avg_sq buffer");
+      t.n[k] = n[j];
+      t.vec[k] = n[j] % 4 == 0 && vg_aligned16(t.param[k]) && vg_aligned16(t.grad[k]) && vg_aligned16(t.ea[k]) &&
+                 vg_aligned16(t.eas[k]) && (!t.mx[k] || vg_aligned16(t.mx[k]));
+      t.first_block[k] = blocks;
+      blocks += (int)((n[j] + kMultiChunk - 1) / kMultiChunk);
+    }
+    t.first_block[t.count] = blocks;
+    hipLaunchKernelGGL(adam_multi_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, t, *cfg);
+    VG_CHECK_LAUNCH("vg_adam_step_multi");
+  }
   return VG_OK;
 }
 

@@ -101,6 +101,7 @@ SIGNATURES = {
     "vg_rmsprop_step": (c_int, [_P, _P, _P, _P, _P, c_size_t, POINTER(RmspropCfg), _P]),
     "vg_rmsprop_step_multi": (c_int, [c_int, _P, _P, _P, _P, _P, _P, POINTER(RmspropCfg), _P]),
     "vg_adam_step": (c_int, [_P, _P, _P, _P, _P, c_size_t, POINTER(AdamCfg), _P]),
+    "vg_adam_step_multi": (c_int, [c_int, _P, _P, _P, _P, _P, _P, POINTER(AdamCfg), _P]),
     "vg_sgd_step": (c_int, [_P, _P, _P, c_size_t, POINTER(SgdCfg), _P]),
     "vg_clamp": (c_int, [_P, c_size_t, c_float, c_float, _P]),
 }

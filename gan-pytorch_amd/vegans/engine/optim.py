@@ -136,15 +136,28 @@ def _adam(opt, grad_scale, lo, hi, decoupled):
                 return np.asarray(scalars_of(float(states[0]["step"])), dtype=np.float64)
 
             shared = graph.host_input((2,), advance, params[0].device)
+        def config(step_size, bc2_sqrt):
+            return AdamCfg(lr, beta1, beta2, group["eps"], group["weight_decay"], step_size, bc2_sqrt,
+                           1 if group["amsgrad"] else 0, 1 if decoupled else 0, sign * grad_scale, lo, hi,
+                           shared.data_ptr() if shared is not None else None)
+
+        if shared is None:
+            for st in states:
+                st["step"] += 1
+        steps = {float(st["step"]) for st in states}
+        if shared is not None or len(steps) == 1:
+            # all tensors of the group are at the same step (the usual case): one launch for the group
+            cfg = config(0.0, 1.0) if shared is not None else config(*scalars_of(steps.pop()))
+            grads = [_grad_mem(p) for p in params]
+            for t in grads:
+                _ptr(t)      # device / dtype check
+            sizes = (c_size_t * len(params))(*[p.numel() for p in params])
+            call("vg_adam_step_multi", len(params), _pointer_array([p.data for p in params]), _pointer_array(grads),
+                 _pointer_array([st["exp_avg"] for st in states]), _pointer_array([st["exp_avg_sq"] for st in states]),
+                 _pointer_array([st.get("max_exp_avg_sq") for st in states]), sizes, byref(cfg), _stream())
+            continue
         for p, state in zip(params, states):
-            if shared is None:
-                state["step"] += 1
-                step_size, bc2_sqrt = scalars_of(float(state["step"]))
-            else:
-                step_size, bc2_sqrt = 0.0, 1.0
-            cfg = AdamCfg(lr, beta1, beta2, group["eps"], group["weight_decay"], step_size, bc2_sqrt,
-                          1 if group["amsgrad"] else 0, 1 if decoupled else 0, sign * grad_scale, lo, hi,
-                          shared.data_ptr() if shared is not None else None)
+            cfg = config(*scalars_of(float(state["step"])))
             call("vg_adam_step", _ptr(p.data), _ptr(_grad_mem(p)), _ptr(state["exp_avg"]), _ptr(state["exp_avg_sq"]),
                  _ptr(state.get("max_exp_avg_sq")), c_size_t(p.numel()), byref(cfg), _stream())
 

@@ -249,6 +249,10 @@ typedef struct vg_adam_cfg {
 } vg_adam_cfg;
 int vg_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, float* max_exp_avg_sq,
                  size_t n, const vg_adam_cfg* cfg, void* stream);
+/* The same update for `count` tensors that share one configuration (hence one step count) in one launch. */
+int vg_adam_step_multi(int count, float* const* params, const float* const* grads, float* const* exp_avgs,
+                       float* const* exp_avg_sqs, float* const* max_exp_avg_sqs, const size_t* n,
+                       const vg_adam_cfg* cfg, void* stream);
 typedef struct vg_sgd_cfg {
   float lr, momentum, dampening, weight_decay;
   int32_t nesterov;
