@@ -28,6 +28,9 @@ from ..engine import graph, ops, optim as hip_optim, parallel
 from ..utils import utils
 
 
+_COPY_STREAMS = {}      # device index -> side stream for batch uploads
+
+
 def _period(value, nr_batches):
     """'0.25e' -> every quarter epoch (at least every batch); ints pass through; None disables."""
     if isinstance(value, str):
@@ -213,8 +216,50 @@ class AbstractGenerativeModel(ABC):
                 t = t.float()
             t = t.to(self.device)
         else:
-            t = torch.from_numpy(np.ascontiguousarray(array, dtype=np.float32)).to(self.device)
+            # pinned staging + asynchronous copy: a copy from pageable memory blocks the host until the stream has
+            # drained, i.e. until the previous iteration has finished, and leaves the GPU idle during the transfer
+            host = torch.from_numpy(np.ascontiguousarray(array, dtype=np.float32)).pin_memory()
+            t = host.to(self.device, non_blocking=True)
         return ops.to_nhwc(t) if t.dim() == 4 else t
+
+    def _device_batches(self, X_train, y_train, batch_size, dp):
+        """The batches of one epoch as device tensors, in the reference's order (AbstractGenerativeModel.py:164-166,
+        319), uploaded one batch ahead on a side stream: while iteration i runs, batch i+1 goes through pinned memory,
+        the copy engine and the layout kernel. Yields X or (X, y)."""
+        device = torch.cuda.current_device()
+        copy_stream = _COPY_STREAMS.get(device)          # kept off the model object, which must stay picklable
+        if copy_stream is None:
+            copy_stream = _COPY_STREAMS[device] = torch.cuda.Stream()
+
+        def upload(batch):
+            parts = batch if isinstance(batch, tuple) else (batch,)
+            copy_stream.wait_stream(torch.cuda.current_stream())     # buffers freed by the main stream may be reused
+            with torch.cuda.stream(copy_stream):
+                out = tuple(self._to_device(dp.shard(part)) for part in parts)
+                done = torch.cuda.Event()
+                done.record(copy_stream)
+            return out, done, (dp.global_rows, getattr(dp, "local_rows", 0))
+
+        def hand_over(item):
+            out, done, rows = item
+            # the sharding context describes the batch being trained on, not the one being uploaded
+            dp.global_rows = rows[0]
+            if hasattr(dp, "local_rows"):
+                dp.local_rows = rows[1]
+            main = torch.cuda.current_stream()
+            main.wait_event(done)
+            for t in out:
+                t.record_stream(main)
+            return out if len(out) > 1 else out[0]
+
+        pending = None
+        for batch in utils.iterate_batches(X_train, y_train, batch_size):
+            nxt = upload(batch)
+            if pending is not None:
+                yield hand_over(pending)
+            pending = nxt
+        if pending is not None:
+            yield hand_over(pending)
 
     # ------------------------------------------------------------------------------------------------------
     # training
@@ -239,10 +284,9 @@ class AbstractGenerativeModel(ABC):
             self._print("---" * 20)
             self._print("EPOCH:", epoch + 1)
             self._print("---" * 20)
-            for batch, X in enumerate(utils.iterate_batches(X_train, None, batch_size)):
+            for batch, X in enumerate(self._device_batches(X_train, None, batch_size, dp)):
                 batch += 1
                 step = epoch * nr_batches + batch
-                X = self._to_device(dp.shard(X))
                 Z = self._draw_latent(len(X), dp)
                 self.train_on_batch(X, Z)
 
@@ -572,11 +616,9 @@ class AbstractConditionalGenerativeModel(AbstractGenerativeModel):
             self._print("---" * 20)
             self._print("EPOCH:", epoch + 1)
             self._print("---" * 20)
-            for batch, (X, y) in enumerate(utils.iterate_batches(X_train, y_train, batch_size)):
+            for batch, (X, y) in enumerate(self._device_batches(X_train, y_train, batch_size, dp)):
                 batch += 1
                 step = epoch * nr_batches + batch
-                X = self._to_device(dp.shard(X))
-                y = self._to_device(dp.shard(y))
                 Z = self._draw_latent(len(X), dp)
                 self.train_on_batch(X, y, Z)
 
