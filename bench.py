@@ -89,7 +89,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--dtype", choices=["fp32", "bf16"], default="fp32",
+    ap.add_argument("--dtype", choices=["fp32", "fp32_split", "bf16"], default="fp32",
                     help="multiplier precision of the convolutions in the timed region (fp32 is the parity-checked mode)")
     ap.add_argument("--no-bf16-extra", action="store_true", help="skip the extra bf16-mode measurement of an fp32 run")
     ap.add_argument("--no-cpu-baseline", action="store_true")

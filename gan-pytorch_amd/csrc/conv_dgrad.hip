@@ -1,6 +1,6 @@
 // vg_conv2d_dgrad: gx = conv_transpose(gy, w) (+ bias): the gradient of a convolution with respect to its
 // input, which is also the forward pass of ConvTranspose2d.
-#include "igemm.h"
+#include "pgemm.h"
 
 int vg_gemm_kn(const float* A, const float* B, const float* bias, int bias_mod, float* out, int M, int Ncols, int K,
                hipStream_t stream, int precision);
@@ -9,13 +9,13 @@ int vg_try_dgrad_thin(const vg_conv_geom* g, const float* gy, const float* w, co
 
 extern "C" int vg_conv2d_dgrad(const vg_conv_geom* g, const float* gy, const float* w, const float* bias,
                                float* gx, void* stream) {
-  return vg_conv2d_dgrad_prec(g, gy, w, bias, gx, VG_PREC_F32, stream);
+  return vg_conv2d_dgrad_prec(g, gy, w, bias, gx, VG_PREC_F32, nullptr, 0, stream);
 }
 
 extern "C" int vg_conv2d_dgrad_prec(const vg_conv_geom* g, const float* gy, const float* w, const float* bias,
-                                    float* gx, int precision, void* stream) {
+                                    float* gx, int precision, void* workspace, size_t workspace_bytes, void* stream) {
   if (int e = vg_check_geom(g, "vg_conv2d_dgrad")) return e;
-  if (precision != VG_PREC_F32 && precision != VG_PREC_BF16)
+  if (precision < VG_PREC_F32 || precision > VG_PREC_F32_SPLIT)
     return vg_fail(VG_ERR_INVALID, "vg_conv2d_dgrad: unknown precision %d", precision);
   VG_REQUIRE(gy && w && gx, "vg_conv2d_dgrad: null tensor pointer");
 
@@ -25,6 +25,7 @@ extern "C" int vg_conv2d_dgrad_prec(const vg_conv_geom* g, const float* gy, cons
 
   if (int r = vg_try_dgrad_thin(g, gy, w, bias, gx, (hipStream_t)stream)) return r < 0 ? r : VG_OK;
 
+  if (precision == VG_PREC_F32_SPLIT && !vg_planes_applicable(1, g)) precision = VG_PREC_F32;
   IgemmParams p{};
   p.A = gy; p.B = w; p.bias = bias; p.out = gx;
   p.N = g->N; p.H = g->H; p.W = g->W; p.Ci = g->Ci; p.Co = g->Co; p.KH = g->kh; p.KW = g->kw;
@@ -43,6 +44,17 @@ extern "C" int vg_conv2d_dgrad_prec(const vg_conv_geom* g, const float* gy, cons
   const int va = (g->Co % 4 == 0 && vg_aligned16(gy)) ? 4 : 1;
   const int vb = (g->Ci % 4 == 0 && vg_aligned16(w)) ? 4 : 1;
   dim3 grid((unsigned)(p.mtiles * p.ntiles), 1, (unsigned)(g->sh * g->sw));
+  if (precision == VG_PREC_F32_SPLIT) {
+    PgemmParams pp{};
+    pp.g = p;
+    if (int e = pgemm_prepare(pp, gy, (long long)g->N * g->Ho * g->Wo * g->Co, w, (long long)g->Co * g->kh * g->kw * g->Ci,
+                              3, workspace, workspace_bytes, (hipStream_t)stream, "vg_conv2d_dgrad"))
+      return e;
+    if (pgemm_launch<MODE_DGRAD, 3>(pp, bm, bn, grid, (hipStream_t)stream) != 0)
+      return vg_fail(VG_ERR_INVALID, "vg_conv2d_dgrad: no plane kernel for tile %dx%d", bm, bn);
+    VG_CHECK_LAUNCH("vg_conv2d_dgrad(planes)");
+    return VG_OK;
+  }
   if (igemm_launch<MODE_DGRAD, true>(p, bm, bn, va, vb, grid, (hipStream_t)stream, precision) != 0)
     return vg_fail(VG_ERR_INVALID, "vg_conv2d_dgrad: no kernel variant for bn=%d va=%d vb=%d", bn, va, vb);
   VG_CHECK_LAUNCH("vg_conv2d_dgrad");

@@ -1,5 +1,5 @@
 // vg_conv2d_fwd: y = conv(x, w) + bias on the f32 MFMA implicit-GEMM core.
-#include "igemm.h"
+#include "pgemm.h"
 
 int vg_check_geom(const vg_conv_geom* g, const char* who) {
   if (!g) return vg_fail(VG_ERR_INVALID, "%s: null geometry", who);
@@ -21,21 +21,22 @@ int vg_try_fwd_thin(const vg_conv_geom* g, const float* x, const float* w, const
 int vg_thin_dgrad_applies(const vg_conv_geom* g);
 
 static int check_precision(int precision, const char* who) {
-  if (precision != VG_PREC_F32 && precision != VG_PREC_BF16) return vg_fail(VG_ERR_INVALID, "%s: unknown precision %d", who, precision);
+  if (precision < VG_PREC_F32 || precision > VG_PREC_F32_SPLIT) return vg_fail(VG_ERR_INVALID, "%s: unknown precision %d", who, precision);
   return 0;
 }
 
 extern "C" int vg_conv2d_fwd(const vg_conv_geom* g, const float* x, const float* w, const float* bias, float* y,
                              void* stream) {
-  return vg_conv2d_fwd_prec(g, x, w, bias, y, VG_PREC_F32, stream);
+  return vg_conv2d_fwd_prec(g, x, w, bias, y, VG_PREC_F32, nullptr, 0, stream);
 }
 
 extern "C" int vg_conv2d_fwd_prec(const vg_conv_geom* g, const float* x, const float* w, const float* bias,
-                                  float* y, int precision, void* stream) {
+                                  float* y, int precision, void* workspace, size_t workspace_bytes, void* stream) {
   if (int e = vg_check_geom(g, "vg_conv2d_fwd")) return e;
   if (int e = check_precision(precision, "vg_conv2d_fwd")) return e;
   VG_REQUIRE(x && w && y, "vg_conv2d_fwd: null tensor pointer");
   if (int r = vg_try_fwd_thin(g, x, w, bias, y, (hipStream_t)stream)) return r < 0 ? r : VG_OK;
+  if (precision == VG_PREC_F32_SPLIT && !vg_planes_applicable(0, g)) precision = VG_PREC_F32;
   IgemmParams p{};
   p.A = x; p.B = w; p.bias = bias; p.out = y;
   p.N = g->N; p.H = g->H; p.W = g->W; p.Ci = g->Ci; p.Co = g->Co; p.KH = g->kh; p.KW = g->kw;
@@ -52,6 +53,17 @@ extern "C" int vg_conv2d_fwd_prec(const vg_conv_geom* g, const float* x, const f
   const int va = (g->Ci % 4 == 0 && vg_aligned16(x)) ? 4 : 1;
   const int vb = (p.Ktot % 4 == 0 && vg_aligned16(w)) ? 4 : 1;
   dim3 grid((unsigned)(p.mtiles * p.ntiles), 1, 1);
+  if (precision == VG_PREC_F32_SPLIT) {
+    PgemmParams pp{};
+    pp.g = p;
+    if (int e = pgemm_prepare(pp, x, (long long)g->N * g->H * g->W * g->Ci, w, (long long)g->Co * p.Ktot, 3, workspace,
+                              workspace_bytes, (hipStream_t)stream, "vg_conv2d_fwd"))
+      return e;
+    if (pgemm_launch<MODE_FWD, 3>(pp, bm, bn, grid, (hipStream_t)stream) != 0)
+      return vg_fail(VG_ERR_INVALID, "vg_conv2d_fwd: no plane kernel for tile %dx%d", bm, bn);
+    VG_CHECK_LAUNCH("vg_conv2d_fwd(planes)");
+    return VG_OK;
+  }
   if (igemm_launch<MODE_FWD, false>(p, bm, bn, va, vb, grid, (hipStream_t)stream, precision) != 0)
     return vg_fail(VG_ERR_INVALID, "vg_conv2d_fwd: no kernel variant for bn=%d va=%d vb=%d", bn, va, vb);
   VG_CHECK_LAUNCH("vg_conv2d_fwd");
@@ -63,6 +75,7 @@ extern "C" int vg_conv2d_fwd_prec(const vg_conv_geom* g, const float* x, const f
 // pixel and the transposed convolution is a single GEMM against the weight viewed as [Co][kh*kw*Ci].
 int vg_gemm_kn(const float* A, const float* B, const float* bias, int bias_mod, float* out, int M, int Ncols, int K,
                hipStream_t stream, int precision) {
+  if (precision == VG_PREC_F32_SPLIT) precision = VG_PREC_F32;   // small and rare: ConvTranspose2d of a latent vector
   IgemmParams p{};
   p.A = A; p.B = B; p.bias = bias; p.out = out;
   p.N = M; p.H = 1; p.W = 1; p.Ci = K; p.Co = Ncols; p.KH = 1; p.KW = 1;

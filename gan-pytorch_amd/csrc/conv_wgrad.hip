@@ -1,7 +1,7 @@
 // vg_conv2d_wgrad: gw[co][kh][kw][ci] = sum over (n,ho,wo) of gy[n][ho][wo][co] * x-window.
 // The contraction runs over all output pixels, so it is split along k across blockIdx.z; every split writes
 // its own f32 slab and a second kernel adds the slabs in split order (bitwise reproducible, no atomics).
-#include "igemm.h"
+#include "pgemm.h"
 
 namespace {
 
@@ -94,6 +94,18 @@ extern "C" size_t vg_conv2d_wgrad_workspace_bytes(const vg_conv_geom* g) {
   return (size_t)pl.nsplit * pl.M * pl.Ncols * sizeof(float);
 }
 
+static size_t slab_bytes(const WgradPlan& pl) {
+  const size_t raw = pl.nsplit > 1 ? (size_t)pl.nsplit * pl.M * pl.Ncols * sizeof(float) : 0;
+  return (raw + 255) / 256 * 256;
+}
+
+extern "C" size_t vg_conv2d_prec_workspace_bytes(int mode, const vg_conv_geom* g, int precision) {
+  if (vg_check_geom(g, "vg_conv2d_prec_workspace_bytes") || mode < 0 || mode > 2) return 0;
+  size_t bytes = mode == 2 ? slab_bytes(wgrad_plan(g)) : 0;
+  if (precision == VG_PREC_F32_SPLIT && vg_planes_applicable(mode, g)) bytes += vg_planes_operand_bytes(mode, g, 3);
+  return bytes;
+}
+
 // Phase 1: the contraction. With more than one split the per-split slabs land in `workspace`, otherwise `gw` is final.
 extern "C" int vg_conv2d_wgrad_partial(const vg_conv_geom* g, const float* gy, const float* x, float* gw, void* workspace,
                                        size_t workspace_bytes, void* stream) {
@@ -103,7 +115,7 @@ extern "C" int vg_conv2d_wgrad_partial(const vg_conv_geom* g, const float* gy, c
 extern "C" int vg_conv2d_wgrad_partial_prec(const vg_conv_geom* g, const float* gy, const float* x, float* gw,
                                             void* workspace, size_t workspace_bytes, int precision, void* stream) {
   if (int e = vg_check_geom(g, "vg_conv2d_wgrad")) return e;
-  if (precision != VG_PREC_F32 && precision != VG_PREC_BF16)
+  if (precision < VG_PREC_F32 || precision > VG_PREC_F32_SPLIT)
     return vg_fail(VG_ERR_INVALID, "vg_conv2d_wgrad: unknown precision %d", precision);
   VG_REQUIRE(gy && x && gw, "vg_conv2d_wgrad: null tensor pointer");
   const WgradPlan pl = wgrad_plan(g);
@@ -125,6 +137,19 @@ extern "C" int vg_conv2d_wgrad_partial_prec(const vg_conv_geom* g, const float* 
   const int va = (g->Co % 4 == 0 && vg_aligned16(gy)) ? 4 : 1;
   const int vb = (g->Ci % 4 == 0 && vg_aligned16(x)) ? 4 : 1;
   dim3 grid((unsigned)(pl.mtiles * pl.ntiles), 1, (unsigned)pl.nsplit);
+  if (precision == VG_PREC_F32_SPLIT && vg_planes_applicable(2, g) && pl.bn != 32) {
+    PgemmParams pp{};
+    pp.g = p;
+    const size_t skip = slab_bytes(pl);
+    if (workspace_bytes < skip) return vg_fail(VG_ERR_WORKSPACE, "vg_conv2d_wgrad: workspace too small for split mode");
+    if (int e = pgemm_prepare(pp, gy, (long long)g->N * g->Ho * g->Wo * g->Co, x, (long long)g->N * g->H * g->W * g->Ci, 3,
+                              (char*)workspace + skip, workspace_bytes - skip, (hipStream_t)stream, "vg_conv2d_wgrad"))
+      return e;
+    if (pgemm_launch<MODE_WGRAD, 3>(pp, pl.bm, pl.bn, grid, (hipStream_t)stream) != 0)
+      return vg_fail(VG_ERR_INVALID, "vg_conv2d_wgrad: no plane kernel for tile %dx%d", pl.bm, pl.bn);
+    VG_CHECK_LAUNCH("vg_conv2d_wgrad(planes)");
+    return VG_OK;
+  }
   if (igemm_launch<MODE_WGRAD, true>(p, pl.bm, pl.bn, va, vb, grid, (hipStream_t)stream, precision) != 0)
     return vg_fail(VG_ERR_INVALID, "vg_conv2d_wgrad: no kernel variant for bn=%d va=%d vb=%d", pl.bn, va, vb);
   VG_CHECK_LAUNCH("vg_conv2d_wgrad");

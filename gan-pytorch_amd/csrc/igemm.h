@@ -30,8 +30,9 @@ typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-enum { PREC_F32 = 0, PREC_BF16 = 1 };
+enum { PREC_F32 = 0, PREC_BF16 = 1, PREC_SPLIT = 2 };   // PREC_SPLIT is served by pgemm.h; here it runs as f32
 
 enum { MODE_FWD = 0, MODE_DGRAD = 1, MODE_WGRAD = 2 };
 
@@ -649,6 +650,7 @@ static inline int igemm_waves(int bm, int bn, int va, int vb, int prec) {
 template <int MODE, bool B_MC>
 static inline int igemm_launch(const IgemmParams& p, int bm, int bn, int va, int vb, dim3 grid, hipStream_t st,
                                int prec = PREC_F32) {
+  if (prec == PREC_SPLIT) prec = PREC_F32;   // shapes the plane GEMM does not serve
 #define IGEMM_CASE_P(BM_, BN_, WM_, VA_, VB_, P_)                                                          \
   if (bm == BM_ && bn == BN_ && va == VA_ && vb == VB_) {                                                  \
     hipLaunchKernelGGL((igemm_kernel<MODE, BM_, BN_, WM_, B_MC, VA_, VB_, P_>), grid, dim3(256), 0, st, p); \
@@ -696,8 +698,9 @@ static inline int igemm_waves_m(int bm, int bn, int nw = 4) {
 // (measured on the DCGAN layers: 256 blocks of 128 rows reach 99-110 TFLOP/s, 512 blocks of 64 rows 102-117). The
 // bf16 kernels were measured with smaller tiles / more blocks as well (64x64 up to 2000 blocks): no gain, same rule.
 static inline int igemm_pick_bm(long long rows, int ntiles, int zdim, int bn, int prec = PREC_F32) {
-  (void)prec;
   if (bn == 32 || rows <= 64) return rows <= 64 && bn != 32 ? 64 : 128;
+  // the split mode is bound by operand traffic into the CUs, which the larger tile halves per flop
+  if (prec == PREC_SPLIT) return ((rows + 127) / 128) * ntiles * zdim < 200 ? 64 : 128;
   const long long blocks128 = ((rows + 127) / 128) * ntiles * zdim;
   return blocks128 < 300 ? 64 : 128;
 }

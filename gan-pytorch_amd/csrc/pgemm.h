@@ -1,0 +1,477 @@
+// Implicit-GEMM convolution core on the bf16 matrix cores (v_mfma_f32_32x32x16_bf16) over operands that were split
+// into bf16 "planes" beforehand.
+//
+// A tensor a (f32) is represented by NP bf16 tensors of the same shape: a0 = bf16(a), a1 = bf16(a - a0),
+// a2 = bf16(a - a0 - a1) (round to nearest even; a0 + a1 + a2 == a exactly).  split_planes_kernel (conv_planes.hip)
+// writes them once per operand, one after the other in a workspace; this kernel then contracts
+//     sum over k of  sum_{i + j < NP}  A_i[m][k] * B_j[k][n]
+// in f32 accumulators.  NP = 3 gives f32-grade products (the dropped terms are below 2^-25 |a b|), NP = 1 is plain
+// bf16.  Taking the split out of the contraction matters because the implicit GEMM reads every activation value
+// kh*kw/(sh*sw) * (number of column tiles) times: converted in the tile loader, the conversions cost more issue
+// slots than the MFMAs they feed.
+//
+// The three contractions and their row/column/k meanings are those of igemm.h.  Tiles are BM x BN x 32, staged
+// global -> registers -> LDS in 16-byte vectors of 8 bf16 (so every channel count involved must be a multiple
+// of 8), double buffered, one barrier per k-step.  A tile whose global image is contiguous along k is kept
+// [row][k] with 80-byte rows (conflict-free ds_read_b128 of a lane's 8 k values); one that is contiguous along
+// the row index is kept [k][row] as loaded and read back with ds_read_b64_tr_b16, which hands lane i of a 16-lane
+// group column i of a 4 x 16 block, i.e. 4 consecutive k of one row - the MFMA operand order - without any register
+// shuffling.  Its row stride is (rows / 2 + 16) dwords, which puts the four k rows of a block 16 banks apart.
+#pragma once
+#include "igemm.h"
+
+struct PgemmParams {
+  IgemmParams g;                 // geometry, extents, output; g.A / g.B unused
+  const __bf16* Ap;              // plane 0 of operand A (fwd: x, dgrad: gy, wgrad: gy)
+  const __bf16* Bp;              // plane 0 of operand B (fwd: w, dgrad: w, wgrad: x)
+  long long a_plane, b_plane;    // elements from one plane to the next
+};
+
+static __device__ __attribute__((aligned(16))) unsigned int vg_zero_page_u[4] = {0u, 0u, 0u, 0u};  // never written
+
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+
+template <int MODE, int BM, int BN, int WAVES_M, int NP, int NW>
+__global__ void __launch_bounds__(NW * 64) pgemm_kernel(const PgemmParams pp) {
+  const IgemmParams& p = pp.g;
+  constexpr int NT = NW * 64;
+  constexpr int BK = 32;
+  constexpr int LDB = 40;                          // bf16 per row of a [row][k] tile
+  constexpr int LDMA = BM + 32, LDMB = BN + 32;    // bf16 per k row of a [k][row] tile
+  constexpr int WAVES_N = NW / WAVES_M;
+  constexpr int TM = BM / (WAVES_M * 32), TN = BN / (WAVES_N * 32);
+  constexpr bool A_MC = (MODE == MODE_WGRAD);
+  constexpr bool B_MC = (MODE != MODE_FWD);
+  static_assert(TM >= 1 && TN >= 1, "tile too small for the wave arrangement");
+
+  constexpr int A_EL = A_MC ? BK * LDMA : BM * LDB;   // bf16 elements per plane
+  constexpr int B_EL = B_MC ? BK * LDMB : BN * LDB;
+  constexpr int A_ALL = NP * A_EL, BUF = NP * (A_EL + B_EL);
+  __shared__ __attribute__((aligned(16))) __bf16 smem[2 * BUF];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wid = tid >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int wm = wid / WAVES_N, wn = wid % WAVES_N;
+
+  // XCD-aware block order. Workgroups are dealt to the 8 XCDs round-robin in dispatch order (x fastest, then z), and
+  // each XCD has its own L2. Every XCD is given a contiguous run of the logical order "z-major, then tile": for the
+  // weight gradient that is whole split-K chunks, whose tiles all read the same pixels (2 + 16 operand tiles feed 32
+  // blocks); for the other modes a run of row tiles with all their column tiles.
+  int mt, nt, zz;
+  {
+    const int tiles = gridDim.x, nblk = gridDim.x * gridDim.z;
+    const int lin = blockIdx.x + gridDim.x * blockIdx.z;
+    const int xcd = lin & 7, q = nblk >> 3, rem = nblk & 7;
+    const int id = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + (lin >> 3);
+    zz = id / tiles;
+    const int t = id - zz * tiles;
+    mt = t / p.ntiles;
+    nt = t - mt * p.ntiles;
+  }
+  const int m0 = mt * BM, n0 = nt * BN;
+
+  // ---- per-mode extents (as igemm.h) ----
+  int M = p.M, Ktot = p.Ktot;
+  int kbeg = 0, kend = p.Ktot;
+  int cls_h = 0, cls_w = 0, off_h = 0, off_w = 0, Hc = 0, Wc = 0, nth = 0, ntw = 0, base_h = 0, base_w = 0;
+  if constexpr (MODE == MODE_DGRAD) {
+    cls_h = zz / p.sw;
+    cls_w = zz - cls_h * p.sw;
+    off_h = ((cls_h - p.ph) % p.sh + p.sh) % p.sh;
+    off_w = ((cls_w - p.pw) % p.sw + p.sw) % p.sw;
+    Hc = off_h < p.H ? (p.H - off_h + p.sh - 1) / p.sh : 0;
+    Wc = off_w < p.W ? (p.W - off_w + p.sw - 1) / p.sw : 0;
+    nth = cls_h < p.KH ? (p.KH - cls_h + p.sh - 1) / p.sh : 0;
+    ntw = cls_w < p.KW ? (p.KW - cls_w + p.sw - 1) / p.sw : 0;
+    base_h = (off_h + p.ph - cls_h) / p.sh;
+    base_w = (off_w + p.pw - cls_w) / p.sw;
+    M = p.N * Hc * Wc;
+    Ktot = nth * ntw * p.Co;
+    kend = Ktot;
+    if (m0 >= M) return;  // block-uniform
+  } else if constexpr (MODE == MODE_WGRAD) {
+    kbeg = zz * p.kchunk;
+    kend = min(kbeg + p.kchunk, p.Ktot);
+  } else {
+    ntw = p.KW;
+  }
+  const int nk = (kend - kbeg + BK - 1) / BK;
+
+  // ---- loader geometry: a thread owns 16-byte units (8 bf16) of each plane ----
+  // [row][k] tile: unit = (row, k8 = 8 * (tid & 3)), rows (tid >> 2) + (NT / 4) * i
+  // [k][row] tile: unit = (k, 8 rows), TPK threads per k row, k rows tid / TPK + (NT / TPK) * i
+  constexpr int UA_RK = (BM * 4 + NT - 1) / NT, UB_RK = (BN * 4 + NT - 1) / NT;
+  constexpr int TPKA = BM / 8, TPKB = BN / 8;
+  constexpr int UA_MC = (BK * TPKA + NT - 1) / NT, UB_MC = (BK * TPKB + NT - 1) / NT;
+  constexpr int UA = A_MC ? UA_MC : UA_RK, UB = B_MC ? UB_MC : UB_RK;
+  auto rowA = [&](int i) -> int { return (tid >> 2) + (NT / 4) * i; };    // [row][k] tiles
+  auto rowB = [&](int i) -> int { return (tid >> 2) + (NT / 4) * i; };
+  auto krowA = [&](int i) -> int { return tid / TPKA + (NT / TPKA) * i; };  // [k][row] tiles
+  auto krowB = [&](int i) -> int { return tid / TPKB + (NT / TPKB) * i; };
+
+  // ---- A loader state ([row][k]: fwd / dgrad) ----
+  int a_img[A_MC ? 1 : UA], a_h[A_MC ? 1 : UA], a_w[A_MC ? 1 : UA];
+  const bool fast = p.fast_div != 0;
+  const int roww = (MODE == MODE_FWD) ? p.Wo : Wc;
+  const int plane = (MODE == MODE_FWD) ? p.Ho * p.Wo : Hc * Wc;
+  const float inv_roww = roww > 0 ? 1.0f / (float)roww : 0.f, inv_plane = plane > 0 ? 1.0f / (float)plane : 0.f;
+  if constexpr (!A_MC) {
+#pragma unroll
+    for (int i = 0; i < UA; ++i) {
+      const int m = m0 + rowA(i);
+      a_img[i] = 0;
+      a_w[i] = 0;
+      a_h[i] = -(1 << 28);
+      if (rowA(i) < BM && m < M) {
+        const int n = vg_div_row(m, plane, inv_plane, fast), rem = m - n * plane;
+        const int a = vg_div_row(rem, roww, inv_roww, fast), b = rem - a * roww;
+        if constexpr (MODE == MODE_FWD) {
+          a_img[i] = n * p.H * p.W;
+          a_h[i] = a * p.sh - p.ph;
+          a_w[i] = b * p.sw - p.pw;
+        } else {
+          a_img[i] = n * p.Ho * p.Wo;
+          a_h[i] = a + base_h;
+          a_w[i] = b + base_w;
+        }
+      }
+    }
+  }
+
+  // ---- B loader state ----
+  // wgrad: the 8 tile columns (kh, kw, ci .. ci+7) of this thread never change along k
+  const int bn8 = n0 + 8 * (tid % TPKB);
+  int b_ta = 0, b_tb = 0, b_ci = 0;
+  if constexpr (MODE == MODE_WGRAD) {
+    const int tap = bn8 / p.Ci;
+    b_ci = bn8 - tap * p.Ci;
+    b_ta = tap / p.KW;
+    b_tb = tap - b_ta * p.KW;
+    if (bn8 >= p.Ncols) b_ta = -(1 << 28);
+  }
+
+  // ---- k-walk state (stepped by 32 per tile, no divisions in the loop) ----
+  int kpos = kbeg;
+  int ak_c = 0, ak_t = 0;
+  const int a_cch = (MODE == MODE_FWD) ? p.Ci : p.Co;
+  const int a_steps = BK / a_cch, a_rem = BK - a_steps * a_cch;
+  const float inv_ntw = ntw > 0 ? 1.0f / (float)ntw : 0.f;
+  if constexpr (!A_MC) {
+    const int k8 = kbeg + 8 * (tid & 3);
+    ak_t = k8 / a_cch;
+    ak_c = k8 - ak_t * a_cch;
+  }
+  int bk_co[(MODE == MODE_DGRAD) ? UB : 1], bk_t[(MODE == MODE_DGRAD) ? UB : 1];
+  if constexpr (MODE == MODE_DGRAD) {
+#pragma unroll
+    for (int i = 0; i < UB; ++i) {
+      const int k = kbeg + krowB(i);
+      bk_t[i] = k / p.Co;
+      bk_co[i] = k - bk_t[i] * p.Co;
+    }
+  }
+  int bp_row[(MODE == MODE_WGRAD) ? UB : 1], bp_wo[(MODE == MODE_WGRAD) ? UB : 1];
+  const int w_steps = (MODE == MODE_WGRAD) ? BK / p.Wo : 0, w_rem = (MODE == MODE_WGRAD) ? BK - w_steps * p.Wo : 0;
+  const float inv_ho = 1.0f / (float)p.Ho;
+  if constexpr (MODE == MODE_WGRAD) {
+#pragma unroll
+    for (int i = 0; i < UB; ++i) {
+      const int pix = kbeg + krowB(i);
+      bp_row[i] = pix / p.Wo;
+      bp_wo[i] = pix - bp_row[i] * p.Wo;
+    }
+  }
+
+  // two register stages: tile t travels through stage t % 2, so its loads are in flight for two k-steps
+  u32x4 ra[2][UA][NP], rb[2][UB][NP];
+
+  // predicated 16-byte load of the same offset in every plane; an invalid unit reads the zero page
+  auto ld_planes = [&](const __bf16* base, long long pstride, size_t off, bool ok, u32x4 (&dst)[NP]) {
+#pragma unroll
+    for (int q = 0; q < NP; ++q) {
+      const void* ptr = ok ? (const void*)(base + (size_t)q * pstride + off) : (const void*)vg_zero_page_u;
+      dst[q] = *reinterpret_cast<const u32x4*>(ptr);
+    }
+  };
+
+  auto load_tiles = [&](int st) {
+    const int kb = kpos;
+    // ---------------- A ----------------
+    if constexpr (!A_MC) {
+      const bool kvalid = kb + 8 * (tid & 3) < kend;
+      const int ak_ta = vg_div_small(ak_t, inv_ntw), ak_tb = ak_t - ak_ta * ntw;
+#pragma unroll
+      for (int i = 0; i < UA; ++i) {
+        if constexpr (MODE == MODE_FWD) {
+          const int hi = a_h[i] + ak_ta, wi = a_w[i] + ak_tb;
+          const bool ok = kvalid && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
+          ld_planes(pp.Ap, pp.a_plane, (size_t)(a_img[i] + hi * p.W + wi) * p.Ci + ak_c, ok, ra[st][i]);
+        } else {
+          const int ho = a_h[i] - ak_ta, wo = a_w[i] - ak_tb;
+          const bool ok = kvalid && (unsigned)ho < (unsigned)p.Ho && (unsigned)wo < (unsigned)p.Wo;
+          ld_planes(pp.Ap, pp.a_plane, (size_t)(a_img[i] + ho * p.Wo + wo) * p.Co + ak_c, ok, ra[st][i]);
+        }
+      }
+    } else {
+      // wgrad A = gy[pixel][co], tile [k][m]
+      const int m8 = m0 + 8 * (tid % TPKA);
+#pragma unroll
+      for (int i = 0; i < UA; ++i) {
+        const int pix = kb + krowA(i);
+        ld_planes(pp.Ap, pp.a_plane, (size_t)pix * p.Co + m8, krowA(i) < BK && pix < kend && m8 < p.Co, ra[st][i]);
+      }
+    }
+    // ---------------- B ----------------
+    if constexpr (!B_MC) {
+      // fwd weights w[co][k]: tile [n][k]
+      const int k8 = kb + 8 * (tid & 3);
+#pragma unroll
+      for (int i = 0; i < UB; ++i) {
+        const int n = n0 + rowB(i);
+        ld_planes(pp.Bp, pp.b_plane, (size_t)n * Ktot + k8, rowB(i) < BN && n < p.Ncols && k8 < kend, rb[st][i]);
+      }
+    } else if constexpr (MODE == MODE_DGRAD) {
+      // weights w[co][kh][kw][ci] read as B[k=(tap,co)][n=ci]
+#pragma unroll
+      for (int i = 0; i < UB; ++i) {
+        const int k = kb + krowB(i);
+        const int bta = vg_div_small(bk_t[i], inv_ntw), btb = bk_t[i] - bta * ntw;
+        const int kh = cls_h + p.sh * bta, kw = cls_w + p.sw * btb;
+        const size_t base = ((size_t)(bk_co[i] * p.KH + kh) * p.KW + kw) * p.Ci;
+        ld_planes(pp.Bp, pp.b_plane, base + bn8, krowB(i) < BK && k < kend && bn8 < p.Ncols, rb[st][i]);
+      }
+    } else {
+      // wgrad B = x window, tile [k=pixel][n=(kh,kw,ci)]
+#pragma unroll
+      for (int i = 0; i < UB; ++i) {
+        const int pix = kb + krowB(i);
+        const int bpn = vg_div_small(bp_row[i], inv_ho), bpho = bp_row[i] - bpn * p.Ho;
+        const int hi = bpho * p.sh - p.ph + b_ta, wi = bp_wo[i] * p.sw - p.pw + b_tb;
+        const bool ok = krowB(i) < BK && pix < kend && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
+        ld_planes(pp.Bp, pp.b_plane, (size_t)((bpn * p.H + hi) * p.W + wi) * p.Ci + b_ci, ok, rb[st][i]);
+      }
+    }
+    // ---------------- advance the k-walk by one tile ----------------
+    kpos += BK;
+    if constexpr (!A_MC) {
+      ak_c += a_rem;
+      const int carry = ak_c >= a_cch ? 1 : 0;
+      ak_c -= carry ? a_cch : 0;
+      ak_t += a_steps + carry;
+    }
+    if constexpr (MODE == MODE_DGRAD) {
+#pragma unroll
+      for (int i = 0; i < UB; ++i) {
+        bk_co[i] += a_rem;
+        const int carry = bk_co[i] >= a_cch ? 1 : 0;
+        bk_co[i] -= carry ? a_cch : 0;
+        bk_t[i] += a_steps + carry;
+      }
+    }
+    if constexpr (MODE == MODE_WGRAD) {
+#pragma unroll
+      for (int i = 0; i < UB; ++i) {
+        bp_wo[i] += w_rem;
+        const int carry = bp_wo[i] >= p.Wo ? 1 : 0;
+        bp_wo[i] -= carry ? p.Wo : 0;
+        bp_row[i] += w_steps + carry;
+      }
+    }
+  };
+
+  auto store_tiles = [&](int buf) {   // tile in stage `buf` -> LDS buffer `buf`
+    __bf16* As = smem + buf * BUF;
+    __bf16* Bs = As + A_ALL;
+#pragma unroll
+    for (int i = 0; i < UA; ++i) {
+      if constexpr (!A_MC) {
+        if (BM * 4 % NT == 0 || rowA(i) < BM) {
+#pragma unroll
+          for (int q = 0; q < NP; ++q)
+            *reinterpret_cast<u32x4*>(&As[q * A_EL + rowA(i) * LDB + 8 * (tid & 3)]) = ra[buf][i][q];
+        }
+      } else {
+        if (BK * TPKA % NT == 0 || krowA(i) < BK) {
+#pragma unroll
+          for (int q = 0; q < NP; ++q)
+            *reinterpret_cast<u32x4*>(&As[q * A_EL + krowA(i) * LDMA + 8 * (tid % TPKA)]) = ra[buf][i][q];
+        }
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < UB; ++i) {
+      if constexpr (!B_MC) {
+        if (BN * 4 % NT == 0 || rowB(i) < BN) {
+#pragma unroll
+          for (int q = 0; q < NP; ++q)
+            *reinterpret_cast<u32x4*>(&Bs[q * B_EL + rowB(i) * LDB + 8 * (tid & 3)]) = rb[buf][i][q];
+        }
+      } else {
+        if (BK * TPKB % NT == 0 || krowB(i) < BK) {
+#pragma unroll
+          for (int q = 0; q < NP; ++q)
+            *reinterpret_cast<u32x4*>(&Bs[q * B_EL + krowB(i) * LDMB + 8 * (tid % TPKB)]) = rb[buf][i][q];
+        }
+      }
+    }
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < TN; ++ni)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.f;
+
+  // Fragment of a [k][row] tile: lane (r, h) needs k = 16 s + 8 h + 0..7 of row `row0 + r`. Two transposed reads of
+  // 4 k each; in a 16-lane group, lane 4 q + c supplies the address of k row q, rows 4 c .. 4 c + 3 of the group's 16.
+  const int tr_q = (lane & 15) >> 2, tr_c = lane & 3, tr_half = (lane >> 4) & 1;
+  auto read_tr = [&](const __bf16* T, int ldm, int row0, int s) -> bf16x8 {
+    const __bf16* a0 = T + (16 * s + 8 * h + tr_q) * ldm + row0 + 16 * tr_half + 4 * tr_c;
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)a0);
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a0 + 4 * ldm));
+    typedef short s16x8 __attribute__((ext_vector_type(8)));
+    const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8, v);
+  };
+
+  // fragment q * T + i is plane q of 32-row tile i
+  auto load_frags = [&](int buf, int s, bf16x8 (&af)[NP * TM], bf16x8 (&bf)[NP * TN]) {
+    const __bf16* As = smem + buf * BUF;
+    const __bf16* Bs = As + A_ALL;
+#pragma unroll
+    for (int q = 0; q < NP; ++q) {
+#pragma unroll
+      for (int mi = 0; mi < TM; ++mi) {
+        const int row0 = (wm * TM + mi) * 32;
+        if constexpr (!A_MC)
+          af[q * TM + mi] = *reinterpret_cast<const bf16x8*>(&As[q * A_EL + (row0 + r) * LDB + 16 * s + 8 * h]);
+        else
+          af[q * TM + mi] = read_tr(As + q * A_EL, LDMA, row0, s);
+      }
+#pragma unroll
+      for (int ni = 0; ni < TN; ++ni) {
+        const int col0 = (wn * TN + ni) * 32;
+        if constexpr (!B_MC)
+          bf[q * TN + ni] = *reinterpret_cast<const bf16x8*>(&Bs[q * B_EL + (col0 + r) * LDB + 16 * s + 8 * h]);
+        else
+          bf[q * TN + ni] = read_tr(Bs + q * B_EL, LDMB, col0, s);
+      }
+    }
+  };
+  // every plane pair (qa, qb) with qa + qb < NP, smallest terms first
+  auto mma_frags = [&](const bf16x8 (&af)[NP * TM], const bf16x8 (&bf)[NP * TN]) {
+#pragma unroll
+    for (int order = NP - 1; order >= 0; --order)
+#pragma unroll
+      for (int qa = 0; qa <= order; ++qa)
+#pragma unroll
+        for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < TN; ++ni)
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[qa * TM + mi], bf[(order - qa) * TN + ni],
+                                                                  acc[mi][ni], 0, 0, 0);
+  };
+
+  bf16x8 afx[NP * TM], bfx[NP * TN], afy[NP * TM], bfy[NP * TN];
+
+  // One k-step on buffer `buf` (two 16-deep slices). On entry afx/bfx hold slice 0 and the other register stage holds
+  // tile kt+1 (loads issued two k-steps ago); it is written to the other buffer under the MFMAs, the loads of tile
+  // kt+3 are issued into the freed stage, and after the barrier slice 0 of the next buffer is fetched under the MFMAs
+  // of slice 1.
+  auto k_step = [&](int kt, int buf) {
+    load_frags(buf, 1, afy, bfy);
+    __builtin_amdgcn_sched_barrier(0);
+    mma_frags(afx, bfx);
+    if (kt + 1 < nk) store_tiles(buf ^ 1);
+    if (kt + 3 < nk) load_tiles(buf ^ 1);
+    __syncthreads();
+    if (kt + 1 < nk) load_frags(buf ^ 1, 0, afx, bfx);
+    __builtin_amdgcn_sched_barrier(0);
+    mma_frags(afy, bfy);
+  };
+
+  if (nk > 0) {
+    load_tiles(0);
+    store_tiles(0);
+    if (nk > 1) load_tiles(1);
+    if (nk > 2) load_tiles(0);
+  }
+  __syncthreads();
+  if (nk > 0) load_frags(0, 0, afx, bfx);
+
+  int kt = 0;
+  for (; kt + 1 < nk; kt += 2) {
+    k_step(kt, 0);
+    k_step(kt + 1, 1);
+  }
+  if (kt < nk) k_step(kt, 0);
+
+  // ---- epilogue: lane holds column (lane&31) and rows (e&3)+8*(e>>2)+4*(lane>>5) of each 32x32 tile ----
+  float* outp = p.out;
+  if constexpr (MODE == MODE_WGRAD) outp += (size_t)zz * p.slab_stride;
+#pragma unroll
+  for (int mi = 0; mi < TM; ++mi) {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int row = m0 + (wm * TM + mi) * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+      if (row >= M) continue;
+      size_t rowoff;
+      if constexpr (MODE == MODE_DGRAD) {
+        const int n = vg_div_row(row, plane, inv_plane, fast), rem = row - n * plane;
+        const int ii = vg_div_row(rem, roww, inv_roww, fast), jj = rem - ii * roww;
+        rowoff = (size_t)((n * p.H + ii * p.sh + off_h) * p.W + jj * p.sw + off_w) * p.Ncols;
+      } else {
+        rowoff = (size_t)row * p.Ncols;
+      }
+#pragma unroll
+      for (int ni = 0; ni < TN; ++ni) {
+        const int col = n0 + (wn * TN + ni) * 32 + r;
+        if (col < p.Ncols) {
+          float v = acc[mi][ni][e];
+          if constexpr (MODE != MODE_WGRAD) {
+            if (p.bias) v += p.bias[col % p.bias_mod];
+          }
+          outp[rowoff + col] = v;
+        }
+      }
+    }
+  }
+}
+
+// Tiles served: 128x128, 128x64, 64x128 (eight waves) and 64x64 (four waves).
+template <int MODE, int NP>
+static inline int pgemm_launch(const PgemmParams& pp, int bm, int bn, dim3 grid, hipStream_t st) {
+  if (bm == 128 && bn == 128) hipLaunchKernelGGL((pgemm_kernel<MODE, 128, 128, 2, NP, 8>), grid, dim3(512), 0, st, pp);
+  else if (bm == 128 && bn == 64) hipLaunchKernelGGL((pgemm_kernel<MODE, 128, 64, 4, NP, 8>), grid, dim3(512), 0, st, pp);
+  else if (bm == 64 && bn == 128) hipLaunchKernelGGL((pgemm_kernel<MODE, 64, 128, 2, NP, 8>), grid, dim3(512), 0, st, pp);
+  else if (bm == 64 && bn == 64) hipLaunchKernelGGL((pgemm_kernel<MODE, 64, 64, 2, NP, 4>), grid, dim3(256), 0, st, pp);
+  else return -1;
+  return 0;
+}
+
+// conv_planes.hip
+size_t vg_planes_bytes(long long elements, int np);   // workspace bytes for the planes of one operand
+int vg_split_planes(const float* in, long long elements, int np, void* planes, hipStream_t st);
+long long vg_plane_stride(long long elements);
+int vg_planes_applicable(int mode, const vg_conv_geom* g);
+size_t vg_planes_operand_bytes(int mode, const vg_conv_geom* g, int np);
+
+// Splits both operands into `workspace` (A's planes first) and fills the plane fields of `pp`.
+static inline int pgemm_prepare(PgemmParams& pp, const float* A, long long a_elems, const float* B, long long b_elems,
+                                int np, void* workspace, size_t workspace_bytes, hipStream_t st, const char* who) {
+  const size_t need = vg_planes_bytes(a_elems, np) + vg_planes_bytes(b_elems, np);
+  if (!workspace || workspace_bytes < need || ((uintptr_t)workspace & 255) != 0)
+    return vg_fail(VG_ERR_WORKSPACE, "%s: split mode needs a 256-byte aligned workspace of %zu bytes, got %zu", who, need,
+                   workspace_bytes);
+  char* ws = (char*)workspace;
+  vg_split_planes(A, a_elems, np, ws, st);
+  vg_split_planes(B, b_elems, np, ws + vg_planes_bytes(a_elems, np), st);
+  pp.Ap = (const __bf16*)ws;
+  pp.Bp = (const __bf16*)(ws + vg_planes_bytes(a_elems, np));
+  pp.a_plane = vg_plane_stride(a_elems);
+  pp.b_plane = vg_plane_stride(b_elems);
+  return 0;
+}

@@ -184,24 +184,27 @@ class inputs_only:
         inputs_only.active = self.prev
 
 
-PRECISIONS = {"fp32": 0, "f32": 0, "float32": 0, "bf16": 1, "bfloat16": 1}
+PRECISIONS = {"fp32": 0, "f32": 0, "float32": 0, "bf16": 1, "bfloat16": 1, "fp32_split": 2, "bf16x3": 2}
+_PRECISION_NAMES = {0: "fp32", 1: "bf16", 2: "fp32_split"}
 _precision = PRECISIONS[os.environ.get("VEGANS_HIP_PRECISION", "fp32").lower()]
 
 
 def set_matmul_precision(name):
-    """Multiplier precision of the convolution / linear contractions: "fp32" (default; exact f32 products, the mode
-    the parity statements are made for) or "bf16" (operands rounded to bf16 inside the matrix cores, f32
-    accumulation; activations, weights, optimizer state and every other kernel stay f32). Returns the previous name."""
+    """Multiplier precision of the convolution / linear contractions: "fp32" (default; f32 MFMA products),
+    "fp32_split" (f32-grade products computed on the bf16 matrix cores: operands split exactly into three bf16 terms,
+    six cross products accumulated in f32; agrees with "fp32" to f32 rounding noise) or "bf16" (operands rounded to
+    bf16 inside the matrix cores, f32 accumulation). Activations, weights, optimizer state and every other kernel stay
+    f32 in all three. Returns the previous name."""
     global _precision
     if name not in PRECISIONS:
         raise ValueError("precision must be one of %s" % sorted(PRECISIONS))
-    previous = "bf16" if _precision == 1 else "fp32"
+    previous = _PRECISION_NAMES[_precision]
     _precision = PRECISIONS[name]
     return previous
 
 
 def matmul_precision():
-    return "bf16" if _precision == 1 else "fp32"
+    return _PRECISION_NAMES[_precision]
 
 
 def _launch_conv(mode, g, fn):
@@ -211,14 +214,24 @@ def _launch_conv(mode, g, fn):
         conv_timer.launch(mode, g, fn)
 
 
+def _conv_workspace(mode, g, device):
+    """(bytes, pointer) of the scratch a contraction needs under the current precision: split-K slabs of the weight
+    gradient and, in the split mode, the bf16 terms of both operands."""
+    nbytes = _hip.load().vg_conv2d_prec_workspace_bytes(mode, ctypes.byref(g.c), _precision)
+    if not nbytes:
+        return 0, None
+    return nbytes, ctypes.c_void_p(workspace(nbytes, device).data_ptr())
+
+
 def raw_conv_fwd(g, x, w, bias):
     x, w = to_nhwc(x), _weight_mem(w)
     _check_shape(x, g.x_shape(), "conv input")
     if w.numel() != g.w_numel():
         raise _hip.HipError("weight has %d elements, geometry expects %d" % (w.numel(), g.w_numel()))
     y = _new_act(g.N, g.Co, g.Ho, g.Wo, x, g.flat)
+    nbytes, wsp = _conv_workspace(0, g, x.device)
     _launch_conv(0, g, lambda: call("vg_conv2d_fwd_prec", ctypes.byref(g.c), _ptr(x), _ptr(w), _ptr(bias), _ptr(y),
-                                    _precision, _stream()))
+                                    _precision, wsp, c_size_t(nbytes), _stream()))
     return y
 
 
@@ -228,8 +241,9 @@ def raw_conv_dgrad(g, gy, w, bias):
     if w.numel() != g.w_numel():
         raise _hip.HipError("weight has %d elements, geometry expects %d" % (w.numel(), g.w_numel()))
     gx = _new_act(g.N, g.Ci, g.H, g.W, gy, g.flat)
+    nbytes, wsp = _conv_workspace(1, g, gy.device)
     _launch_conv(1, g, lambda: call("vg_conv2d_dgrad_prec", ctypes.byref(g.c), _ptr(gy), _ptr(w), _ptr(bias), _ptr(gx),
-                                    _precision, _stream()))
+                                    _precision, wsp, c_size_t(nbytes), _stream()))
     return gx
 
 
@@ -243,12 +257,10 @@ def raw_conv_wgrad(g, gy, x, w_shape):
         gw = torch.empty(w_shape, dtype=torch.float32, device=x.device)
     if gw.numel() != g.w_numel():
         raise _hip.HipError("weight gradient shape %s does not match the geometry" % (tuple(w_shape),))
-    nbytes = _hip.load().vg_conv2d_wgrad_workspace_bytes(ctypes.byref(g.c))
-    ws = workspace(nbytes, x.device) if nbytes else None
-    wsp = ctypes.c_void_p(ws.data_ptr()) if ws is not None else None
+    nbytes, wsp = _conv_workspace(2, g, x.device)
     _launch_conv(2, g, lambda: call("vg_conv2d_wgrad_partial_prec", ctypes.byref(g.c), _ptr(gy), _ptr(x), _ptr(gw), wsp,
                                     c_size_t(nbytes), _precision, _stream()))
-    if nbytes:
+    if _hip.load().vg_conv2d_wgrad_workspace_bytes(ctypes.byref(g.c)):
         call("vg_conv2d_wgrad_reduce", ctypes.byref(g.c), _ptr(gw), wsp, _stream())
     return gw
 

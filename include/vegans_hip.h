@@ -80,14 +80,22 @@ int vg_conv2d_wgrad_reduce(const vg_conv_geom* g, float* gw, const void* workspa
 
 /* The same three contractions with a choice of multiplier precision (the north-star configuration names a bf16 mode
  * next to fp32): VG_PREC_F32 = exact f32 products (what the un-suffixed entry points do); VG_PREC_BF16 = operands
- * rounded to bf16 (nearest even) on their way into the matrix cores, f32 accumulation, f32 tensors in memory.
+ * rounded to bf16 (nearest even) on their way into the matrix cores, f32 accumulation, f32 tensors in memory;
+ * VG_PREC_F32_SPLIT = f32-grade products on the bf16 matrix cores: every operand is split exactly into three bf16
+ * terms and the six leading cross products are accumulated in f32 (the neglected ones lie below 2^-25 of |a b|, less
+ * than the rounding of one f32 multiplication), so results agree with VG_PREC_F32 to f32 rounding noise.
  * Shapes the bf16 tiles do not cover (operands that are not 16-byte vectors, e.g. a 3-channel image stem, and the
- * bandwidth-bound thin kernels) run in f32 under either setting. */
-enum { VG_PREC_F32 = 0, VG_PREC_BF16 = 1 };
+ * bandwidth-bound thin kernels) run in f32 under every setting.
+ * Workspace: vg_conv2d_prec_workspace_bytes(mode, g, precision) bytes, 256-byte aligned (0 = none needed). The split
+ * mode keeps the bf16 terms of both operands there (written by a splitting kernel ahead of the contraction); for
+ * mode 2 the size includes the split-K slabs of vg_conv2d_wgrad_workspace_bytes, which come first, so
+ * vg_conv2d_wgrad_reduce takes the same pointer. */
+enum { VG_PREC_F32 = 0, VG_PREC_BF16 = 1, VG_PREC_F32_SPLIT = 2 };
+size_t vg_conv2d_prec_workspace_bytes(int mode, const vg_conv_geom* g, int precision);   /* mode 0 fwd, 1 dgrad, 2 wgrad */
 int vg_conv2d_fwd_prec(const vg_conv_geom* g, const float* x, const float* w, const float* bias, float* y,
-                       int precision, void* stream);
+                       int precision, void* workspace, size_t workspace_bytes, void* stream);
 int vg_conv2d_dgrad_prec(const vg_conv_geom* g, const float* gy, const float* w, const float* bias, float* gx,
-                         int precision, void* stream);
+                         int precision, void* workspace, size_t workspace_bytes, void* stream);
 int vg_conv2d_wgrad_partial_prec(const vg_conv_geom* g, const float* gy, const float* x, float* gw, void* workspace,
                                  size_t workspace_bytes, int precision, void* stream);
 

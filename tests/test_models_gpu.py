@@ -76,6 +76,22 @@ def _fit(model, case, X, y):
 
 @pytest.mark.parametrize("name", gu.names())
 def test_fit_matches_reference_fixture(gpu, name):
+    _check_fit_against_fixture(name)
+
+
+@pytest.mark.parametrize("name", ["wgangp_dcgan64", "lsgan_dcgan16", "cwgangp_onehot"])
+def test_split_mode_meets_the_fp32_statement(gpu, name):
+    """The split mode (f32-grade products from three bf16 terms per operand) against the reference's recorded fp32 run,
+    with the very tolerances of the fp32 test: losses, trained parameters and eval-mode samples."""
+    from vegans.engine import ops
+    previous = ops.set_matmul_precision("fp32_split")
+    try:
+        _check_fit_against_fixture(name)
+    finally:
+        ops.set_matmul_precision(previous)
+
+
+def _check_fit_against_fixture(name):
     fx = gu.load(name)
     case = fx["meta"]
     nets = gu.build_nets(case)

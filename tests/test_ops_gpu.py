@@ -127,6 +127,75 @@ def test_bf16_mode_rounds_operands_to_nearest_even(gpu):
     assert 1e-5 < err < 2e-2, err       # really ran in bf16, and stays within the mode's stated tolerance
 
 
+SPLIT_CASES = [
+    # kind, N, Cin, H, W, Cout, k, s, p      (channel counts that are multiples of 8 take the plane GEMM)
+    ("conv", 2, 64, 16, 16, 128, 4, 2, 1),     # 128x128 tiles, all three modes
+    ("conv", 3, 16, 9, 7, 40, 3, 1, 1),        # ragged rows and columns, K = 144 (partial last k-step)
+    ("conv", 130, 8, 4, 4, 72, 1, 1, 0),       # 1x1, K = 8: a single partial k-step; input gradient has 8 columns (f32 path)
+    ("conv", 2, 48, 12, 12, 56, 3, 2, 0),      # stride 2 without padding: parity classes of different size
+    ("conv", 1, 72, 20, 20, 136, 5, 1, 2),     # 5x5, two column tiles with a ragged second one
+    ("conv", 16, 128, 8, 8, 256, 4, 2, 1),     # enough rows for several split-K chunks in the weight gradient
+    ("convT", 2, 64, 4, 4, 40, 4, 2, 1),       # DCGAN upsample: dgrad contraction as forward
+    ("convT", 2, 24, 4, 4, 40, 5, 3, 1),       # stride 3, k = 5
+    ("conv", 4, 12, 8, 8, 20, 3, 1, 1),        # channels not multiples of 8: served by the f32 kernels
+]
+
+
+@pytest.mark.parametrize("case", SPLIT_CASES)
+def test_split_mode_matches_f32_accuracy(gpu, case):
+    """The split mode (three bf16 terms per operand, six products, f32 accumulation) claims f32-grade results: measured
+    against a float64 evaluation, its error must stay within 1e-5 of the output scale and within twice the error of the
+    f32 MFMA kernels plus rounding noise, on every contraction."""
+    from vegans.engine import ops
+    kind, N, Ci, H, W, Co, k, s, p = case
+    g = torch.Generator().manual_seed(sum(case[1:]))
+    x = torch.randn(N, Ci, H, W, generator=g)
+    if kind == "conv":
+        w = torch.randn(Co, Ci, k, k, generator=g) * 0.1
+        ref = lambda a, b: F.conv2d(a, b, None, stride=s, padding=p)
+        dut = lambda a, b: ops.conv2d(a, b, None, (s, s), (p, p))
+    else:
+        w = torch.randn(Ci, Co, k, k, generator=g) * 0.1
+        ref = lambda a, b: F.conv_transpose2d(a, b, None, stride=s, padding=p)
+        dut = lambda a, b: ops.conv_transpose2d(a, b, None, (s, s), (p, p))
+    xr, wr = x.double().requires_grad_(True), w.double().requires_grad_(True)
+    yr = ref(xr, wr)
+    gy = torch.randn(yr.shape, generator=g)
+    yr.backward(gy.double())
+    want = (yr.detach(), xr.grad, wr.grad)
+
+    def run(precision):
+        previous = ops.set_matmul_precision(precision)
+        try:
+            xd, wd = x.to(gpu).requires_grad_(True), w.to(gpu).requires_grad_(True)
+            y = dut(xd, wd)
+            y.backward(gy.to(gpu))
+        finally:
+            ops.set_matmul_precision(previous)
+        return [float((t.detach().cpu().double() - r).abs().max() / r.abs().max()) for t, r in zip((y, xd.grad, wd.grad), want)]
+
+    base, split = run("fp32"), run("fp32_split")
+    for name, e0, e1 in zip(("forward", "input gradient", "weight gradient"), base, split):
+        assert e1 <= 1e-5, "%s: split-mode error %.3e" % (name, e1)
+        assert e1 <= 2.0 * e0 + 2e-7, "%s: split-mode error %.3e vs %.3e in f32" % (name, e1, e0)
+
+
+def test_split_mode_uses_the_plane_kernels(gpu):
+    """The eligible shapes really go through the split (a workspace for the bf16 terms is requested), others do not."""
+    import ctypes
+    from vegans import _hip
+    from vegans.engine import ops
+    lib = _hip.load()
+    g = ops.Geom(2, 16, 16, 64, 128, 4, 4, 2, 2, 1, 1)
+    for mode in (0, 1):
+        assert lib.vg_conv2d_prec_workspace_bytes(mode, ctypes.byref(g.c), 2) > 0
+        assert lib.vg_conv2d_prec_workspace_bytes(mode, ctypes.byref(g.c), 0) == 0
+    slabs = lib.vg_conv2d_wgrad_workspace_bytes(ctypes.byref(g.c))
+    assert lib.vg_conv2d_prec_workspace_bytes(2, ctypes.byref(g.c), 2) > (slabs + 255) // 256 * 256
+    stem = ops.Geom(2, 16, 16, 3, 64, 4, 4, 2, 2, 1, 1)
+    assert lib.vg_conv2d_prec_workspace_bytes(0, ctypes.byref(stem.c), 2) == 0
+
+
 CONVT_CASES = [
     # N, Cin, Hi, Wi, Cout, k, s, p
     (4, 100, 1, 1, 64, 4, 1, 0),    # latent vector -> 4x4 (single GEMM path)
