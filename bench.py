@@ -91,7 +91,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--dtype", choices=["fp32", "fp32_split", "bf16"], default="fp32",
                     help="multiplier precision of the convolutions in the timed region (fp32 is the parity-checked mode)")
-    ap.add_argument("--no-bf16-extra", action="store_true", help="skip the extra bf16-mode measurement of an fp32 run")
+    ap.add_argument("--no-bf16-extra", action="store_true", help="skip the extra bf16-mode and split-mode measurements of an fp32 run")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     args = ap.parse_args()
@@ -153,26 +153,31 @@ def main():
 
     # The north-star configuration names a bf16 mode next to fp32: measure it too (same model object, same batches;
     # the changed precision makes train_on_batch record new graphs), reported beside the fp32 figure, never as `value`.
-    bf16_extra = None
+    # Likewise the split mode, which computes f32-grade products on the bf16 matrix cores.
+    extras = {}
+    notes = {"bf16": "convolutions with bf16 matrix-core operands and f32 accumulation; everything else f32; "
+                     "losses within 2e-2 of the fp32 reference (tests/test_models_gpu.py)",
+             "fp32_split": "convolution operands split exactly into three bf16 terms, six bf16 MFMA products per f32 "
+                           "product, f32 accumulation; error against float64 no larger than the f32 MFMA kernels' "
+                           "(tests/test_ops_gpu.py) and the fp32 parity tolerances hold (tests/test_models_gpu.py)"}
     if args.dtype == "fp32" and not args.no_bf16_extra:
-        ops.set_matmul_precision("bf16")
-        for i in range(SETUP_STEPS + args.warmup):
-            step(i)
-        fence()
-        t1 = time.perf_counter()
-        for i in range(args.steps):
-            step(i)
-        fence()
-        bf16_elapsed = time.perf_counter() - t1
-        ops.set_matmul_precision("fp32")
-        if world > 1:
-            t = torch.tensor([bf16_elapsed], device="cuda", dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            bf16_elapsed = float(t.item())
-        bf16_extra = {"value": round(global_batch * args.steps / bf16_elapsed, 2), "unit": "images/s",
-                      "ms_per_step": round(1e3 * bf16_elapsed / args.steps, 3),
-                      "note": "convolutions with bf16 matrix-core operands and f32 accumulation; everything else f32; "
-                              "losses within 2e-2 of the fp32 reference (tests/test_models_gpu.py)"}
+        for mode in ("bf16", "fp32_split"):
+            ops.set_matmul_precision(mode)
+            for i in range(SETUP_STEPS + args.warmup):
+                step(i)
+            fence()
+            t1 = time.perf_counter()
+            for i in range(args.steps):
+                step(i)
+            fence()
+            mode_elapsed = time.perf_counter() - t1
+            ops.set_matmul_precision("fp32")
+            if world > 1:
+                t = torch.tensor([mode_elapsed], device="cuda", dtype=torch.float64)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                mode_elapsed = float(t.item())
+            extras[mode + "_mode"] = {"value": round(global_batch * args.steps / mode_elapsed, 2), "unit": "images/s",
+                                      "ms_per_step": round(1e3 * mode_elapsed / args.steps, 3), "note": notes[mode]}
 
     # Per-kernel durations for the roofline entry. Kernels inside a replayed graph cannot be bracketed one by one, so
     # the same iterations run again eagerly with a start/stop event pair around every convolution launch, on the
@@ -207,7 +212,7 @@ def main():
             "metric": "training images/sec (G+D step) DCGAN-64 WGAN-GP",
             "value": round(value, 2), "unit": "images/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32" if args.dtype == "fp32" else "bf16", "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None, "dtype": {"fp32": "f32", "bf16": "bf16", "fp32_split": "f32 (3xbf16 split)"}[args.dtype], "data": "synthetic",
             "config": {"workload": "WassersteinGANGP DCGAN-64 (ngf=ndf=64, BatchNorm critic), 3x64x64, z=100, "
                                    "batch 256 per GPU, %s, steps G1:D1, RMSprop" % args.dtype,
                        "global_batch": global_batch, "parallelism": "dp%d" % world if world > 1 else "single"},
@@ -230,8 +235,7 @@ def main():
             }
             out["conv_kernels"] = {"ms_per_step": round(all_ms / ROOFLINE_STEPS, 3),
                                    "aggregate_tflops": round(all_fl / (all_ms * 1e-3) / 1e12, 2)}
-        if bf16_extra is not None:
-            out["bf16_mode"] = bf16_extra
+        out.update(extras)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out))
