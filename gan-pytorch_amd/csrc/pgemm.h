@@ -381,14 +381,17 @@ __global__ void __launch_bounds__(NW * 64) pgemm_kernel(const PgemmParams pp) {
   // tile kt+1 (loads issued two k-steps ago); it is written to the other buffer under the MFMAs, the loads of tile
   // kt+3 are issued into the freed stage, and after the barrier slice 0 of the next buffer is fetched under the MFMAs
   // of slice 1.
-  auto k_step = [&](int kt, int buf) {
+  // `more` = tiles kt+1 and kt+3 are known to exist (the branch-free form the steady-state loop uses: with
+  // conditional loads in the loop body the compiler can no longer count which loads are outstanding at the LDS store
+  // and waits for all of them, the stage loaded one k-step ago included).
+  auto k_step = [&](int kt, int buf, bool more) {
     load_frags(buf, 1, afy, bfy);
     __builtin_amdgcn_sched_barrier(0);
     mma_frags(afx, bfx);
-    if (kt + 1 < nk) store_tiles(buf ^ 1);
-    if (kt + 3 < nk) load_tiles(buf ^ 1);
+    if (more || kt + 1 < nk) store_tiles(buf ^ 1);
+    if (more || kt + 3 < nk) load_tiles(buf ^ 1);
     __syncthreads();
-    if (kt + 1 < nk) load_frags(buf ^ 1, 0, afx, bfx);
+    if (more || kt + 1 < nk) load_frags(buf ^ 1, 0, afx, bfx);
     __builtin_amdgcn_sched_barrier(0);
     mma_frags(afy, bfy);
   };
@@ -403,11 +406,15 @@ __global__ void __launch_bounds__(NW * 64) pgemm_kernel(const PgemmParams pp) {
   if (nk > 0) load_frags(0, 0, afx, bfx);
 
   int kt = 0;
-  for (; kt + 1 < nk; kt += 2) {
-    k_step(kt, 0);
-    k_step(kt + 1, 1);
+  for (; kt + 4 < nk; kt += 2) {     // steady state: every tile touched exists
+    k_step(kt, 0, true);
+    k_step(kt + 1, 1, true);
   }
-  if (kt < nk) k_step(kt, 0);
+  for (; kt + 1 < nk; kt += 2) {
+    k_step(kt, 0, false);
+    k_step(kt + 1, 1, false);
+  }
+  if (kt < nk) k_step(kt, 0, false);
 
   // ---- epilogue: lane holds column (lane&31) and rows (e&3)+8*(e>>2)+4*(lane>>5) of each 32x32 tile ----
   float* outp = p.out;
