@@ -141,6 +141,56 @@ def patch_discriminator(in_channels, width=16):
         nn.Conv2d(width * 2, 1, 3, 1, 1), nn.Sigmoid())
 
 
+class UNet(nn.Module):
+    """pix2pix U-Net: `depth` stride-2 4x4 convolutions down to a bottleneck, as many transposed convolutions up, each
+    up block's output concatenated with the mirrored down block's (skip connections); BatchNorm everywhere except the
+    outermost and innermost blocks; no dropout (its random stream could not be shared between implementations).
+    The blocks are direct attributes, first convolution first, which is what VeGANs' input check walks."""
+
+    def __init__(self, in_channels, out_channels=3, width=64, depth=8):
+        super().__init__()
+        self.depth = depth
+        chans = [min(width * 2 ** i, width * 8) for i in range(depth)]
+        c = in_channels
+        for i, co in enumerate(chans):
+            layers = [] if i == 0 else [nn.LeakyReLU(0.2)]
+            layers.append(nn.Conv2d(c, co, 4, 2, 1, bias=(i == 0 or i == depth - 1)))
+            if 0 < i < depth - 1:
+                layers.append(nn.BatchNorm2d(co))
+            setattr(self, "down%d" % i, nn.Sequential(*layers))
+            c = co
+        for i in reversed(range(depth)):
+            cin = chans[i] if i == depth - 1 else chans[i] * 2
+            cout = chans[i - 1] if i > 0 else out_channels
+            layers = [nn.ReLU(), nn.ConvTranspose2d(cin, cout, 4, 2, 1, bias=(i == 0))]
+            if i > 0:
+                layers.append(nn.BatchNorm2d(cout))
+            setattr(self, "up%d" % i, nn.Sequential(*layers))
+        self.output = nn.Sigmoid()
+
+    def forward(self, x):
+        skips = []
+        for i in range(self.depth):
+            x = getattr(self, "down%d" % i)(x)
+            skips.append(x)
+        skips.pop()
+        for i in reversed(range(self.depth)):
+            x = getattr(self, "up%d" % i)(x)
+            if skips:
+                x = torch.cat([x, skips.pop()], 1)
+        return self.output(x)
+
+
+def patchgan_discriminator(in_channels, width=64):
+    """The 70x70 PatchGAN of pix2pix: C64-C128-C256 at stride 2, C512 and the 1-channel head at stride 1, Sigmoid."""
+    return nn.Sequential(
+        nn.Conv2d(in_channels, width, 4, 2, 1), nn.LeakyReLU(0.2),
+        nn.Conv2d(width, width * 2, 4, 2, 1, bias=False), nn.BatchNorm2d(width * 2), nn.LeakyReLU(0.2),
+        nn.Conv2d(width * 2, width * 4, 4, 2, 1, bias=False), nn.BatchNorm2d(width * 4), nn.LeakyReLU(0.2),
+        nn.Conv2d(width * 4, width * 8, 4, 1, 1, bias=False), nn.BatchNorm2d(width * 8), nn.LeakyReLU(0.2),
+        nn.Conv2d(width * 8, 1, 4, 1, 1), nn.Sigmoid())
+
+
 def synthetic_images(n, shape, low=-1.0, high=1.0, seed=0):
     return np.random.default_rng(seed).uniform(low, high, (n, *shape)).astype(np.float32)
 

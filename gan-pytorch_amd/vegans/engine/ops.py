@@ -46,6 +46,8 @@ def to_nhwc(t):
         return t
     if not t.is_contiguous():
         t = _plain_contiguous(t)
+        if t.is_contiguous(memory_format=CL):
+            return t
     n, c, h, w = t.shape
     out = torch.empty((n, c, h, w), dtype=t.dtype, device=t.device, memory_format=CL)
     call("vg_nchw_to_nhwc", _ptr(t), _ptr(out), n, c, h * w, _stream())
@@ -58,7 +60,7 @@ def to_nchw(t):
     if t.dim() != 4 or t.is_contiguous():
         return t if t.is_contiguous() else _plain_contiguous(t)
     if not t.is_contiguous(memory_format=CL):
-        return _plain_contiguous(t)
+        return to_nchw(_plain_contiguous(t))
     n, c, h, w = t.shape
     out = torch.empty((n, c, h, w), dtype=t.dtype, device=t.device)
     call("vg_nhwc_to_nchw", _ptr(t), _ptr(out), n, c, h * w, _stream())
@@ -66,8 +68,22 @@ def to_nchw(t):
 
 
 def _plain_contiguous(t):
-    # Exotic strides (slices, expands) do not occur on the training path; refuse instead of silently running a
-    # stock copy kernel.
+    # A channel slice of an NHWC activation (or a column slice of a [rows][C] one) is what autograd hands back for each
+    # input of a user module's torch.cat along dim 1 (U-Net skip connections): compact it. Other exotic strides
+    # (expands, spatial slices) do not occur on the training path; refuse instead of silently running a stock copy
+    # kernel.
+    shape, stride = tuple(t.shape), tuple(t.stride())
+    if t.dim() == 4:
+        n, c, h, w = shape
+        ctot = stride[3]
+        if stride[1] == 1 and ctot > c and stride[2] == w * ctot and stride[0] == h * w * ctot:
+            out = torch.empty(shape, dtype=t.dtype, device=t.device, memory_format=CL)
+            call("vg_slice_channels", _ptr(t), ctot, 0, c, _ptr(out), c_size_t(n * h * w), _stream())
+            return out
+    if t.dim() == 2 and stride[1] == 1 and stride[0] > shape[1]:
+        out = torch.empty(shape, dtype=t.dtype, device=t.device)
+        call("vg_slice_channels", _ptr(t), stride[0], 0, shape[1], _ptr(out), c_size_t(shape[0]), _stream())
+        return out
     raise _hip.HipError("tensor with strides %s (shape %s) is neither NCHW- nor NHWC-contiguous" %
                         (tuple(t.stride()), tuple(t.shape)))
 

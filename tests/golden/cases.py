@@ -38,6 +38,10 @@ def build_nets(case):
         g = cfg.seeded_init(cfg.img2img_generator(in_channels=2 + 3, out_channels=3, width=4), 1)
         d = cfg.seeded_init(cfg.patch_discriminator(in_channels=6, width=4), 2)
         return g, d, None
+    if k == "unet":
+        g = cfg.seeded_init(cfg.UNet(in_channels=2 + 3, out_channels=3, width=4, depth=5), 1)
+        d = cfg.seeded_init(cfg.patchgan_discriminator(in_channels=6, width=4), 2)
+        return g, d, None
     if k == "cond_vec":
         from torch import nn
         g = cfg.seeded_init(nn.Sequential(nn.Linear(18, 32), nn.LeakyReLU(0.2), nn.BatchNorm1d(32), nn.Linear(32, 20),
@@ -73,6 +77,8 @@ CASES = {
                             x_dim=(1, 32, 32), z_dim=(1, 4, 4), y_dim=(10,), batch=8, n=16, data_range=(0.0, 1.0)),
     "pix2pix_small": dict(cls="ConditionalPix2Pix", algo="pix2pix", nets="img2img", x_dim=(3, 16, 16), z_dim=2,
                           y_dim=(3, 16, 16), batch=4, n=8, data_range=(0.0, 1.0)),
+    "pix2pix_unet": dict(cls="ConditionalPix2Pix", algo="pix2pix", nets="unet", x_dim=(3, 32, 32), z_dim=2,
+                         y_dim=(3, 32, 32), batch=4, n=8, data_range=(0.0, 1.0)),
     "clrgan_vec": dict(cls="ConditionalLRGAN", algo="lrgan", nets="cond_vec", x_dim=(20,), z_dim=(8,), y_dim=(10,), batch=8,
                        n=16),
 }

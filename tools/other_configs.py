@@ -1,5 +1,5 @@
 """Throughput of the other BASELINE configurations' per-GPU shapes (not the headline metric): LSGAN on DCGAN-128 at
-batch 256 (the per-GPU share of the 8-GPU configuration) and ConditionalPix2Pix at 3x256x256, batch 64.
+batch 256 (the per-GPU share of the 8-GPU configuration) and ConditionalPix2Pix (U-Net-256 + PatchGAN) at 3x256x256, batch 64.
     python tools/other_configs.py [steps]
 """
 import contextlib
@@ -47,8 +47,8 @@ def main():
     torch.cuda.empty_cache()
 
     with contextlib.redirect_stdout(io.StringIO()):
-        G = cfg.seeded_init(cfg.img2img_generator(in_channels=4 + 3, out_channels=3, width=16), 1)
-        D = cfg.seeded_init(cfg.patch_discriminator(in_channels=6, width=16), 2)
+        G = cfg.seeded_init(cfg.UNet(in_channels=4 + 3, out_channels=3, width=64, depth=8), 1, 0.02)
+        D = cfg.seeded_init(cfg.patchgan_discriminator(in_channels=6, width=64), 2, 0.02)
         m = gan.ConditionalPix2Pix(G, D, x_dim=(3, 256, 256), z_dim=4, y_dim=(3, 256, 256), folder=None,
                                    fixed_noise_size=2)
     m._create_steps(None)
@@ -56,10 +56,15 @@ def main():
     X = m._to_device(cfg.synthetic_images(64, (3, 256, 256), 0.0, 1.0, seed=1))
     y = m._to_device(cfg.synthetic_images(64, (3, 256, 256), 0.0, 1.0, seed=2))
     Z = torch.randn(64, 4, device="cuda")
-    dt = timed(m, (X, y, Z), steps)
-    print("ConditionalPix2Pix (conv encoder-decoder + patch discriminator, width 16), 3x256x256, batch 64, Adam, fp32: "
-          "%.2f ms/iteration, %.0f images/s" % (1e3 * dt, 64 / dt))
-
+    for prec in ("fp32", "fp32_split", "bf16"):
+        from vegans.engine import ops
+        previous = ops.set_matmul_precision(prec)
+        try:
+            dt = timed(m, (X, y, Z), steps)
+        finally:
+            ops.set_matmul_precision(previous)
+        print("ConditionalPix2Pix (U-Net-256 with skip connections, 8 down / 8 up, width 64; 70x70 PatchGAN), 3x256x256, "
+              "batch 64, Adam, %s: %.2f ms/iteration, %.0f images/s" % (prec, 1e3 * dt, 64 / dt))
 
 if __name__ == "__main__":
     main()
