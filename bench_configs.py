@@ -3,8 +3,9 @@ same definitions feed the HIP engine, the CPU oracle and the golden-vector gener
 
 Architectures: the DCGAN generator/critic pair of the PyTorch DCGAN tutorial (credited by the reference's
 README.md:101) at 64x64 and 128x128; the MLP pair of examples/example_input_formats.py:141-165; the conditional
-convolutional pair of notebooks/03_mnist-conditional.ipynb; a small encoder-decoder / patch critic pair for the
-image-to-image configuration (the reference ships no U-Net).
+convolutional pair of notebooks/03_mnist-conditional.ipynb; for the image-to-image configuration a small
+encoder-decoder / patch critic pair and the pix2pix U-Net (skip concatenations) / 70x70 PatchGAN pair (the reference
+ships neither; its own image-to-image example is a plain encoder-decoder, examples/example_image_to_image.py:35-99).
 """
 import numpy as np
 import torch
