@@ -160,7 +160,7 @@ def main():
              "fp32_split": "convolution operands split exactly into three bf16 terms, six bf16 MFMA products per f32 "
                            "product, f32 accumulation; error against float64 no larger than the f32 MFMA kernels' "
                            "(tests/test_ops_gpu.py) and the fp32 parity tolerances hold (tests/test_models_gpu.py)"}
-    if args.dtype == "fp32" and not args.no_bf16_extra:
+    if args.dtype == "fp32" and not args.no_bf16_extra and world == 1:     # extras on the single-GPU line only
         for mode in ("bf16", "fp32_split"):
             ops.set_matmul_precision(mode)
             for i in range(SETUP_STEPS + args.warmup):
