@@ -2,7 +2,7 @@
 
     python bench.py --gpus N --steps K --warmup W
 
-Workload (BASELINE.json configs[1]): WassersteinGANGP, DCGAN-64 generator / BatchNorm critic (ngf = ndf = 64),
+Workload (the north-star configuration): WassersteinGANGP, DCGAN-64 generator / BatchNorm critic (ngf = ndf = 64),
 synthetic 3x64x64 images, z_dim = [100,1,1], batch 256 per GPU, fp32, steps G:1 / D:1, RMSprop.  One "step" is one
 pass of the hot loop body over one batch that already sits in HBM (G sub-step + D sub-step with gradient penalty).
 With N > 1 (launched by torch.distributed.run, one rank per GPU) the global batch is 256*N (weak scaling), sharded

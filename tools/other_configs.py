@@ -1,4 +1,4 @@
-"""Throughput of the other BASELINE configurations' per-GPU shapes (not the headline metric): LSGAN on DCGAN-128 at
+"""Throughput of the other benchmark configurations' per-GPU shapes (not the headline metric): LSGAN on DCGAN-128 at
 batch 256 (the per-GPU share of the 8-GPU configuration) and ConditionalPix2Pix (U-Net-256 + PatchGAN) at 3x256x256, batch 64.
     python tools/other_configs.py [steps]
 """
