@@ -9,11 +9,12 @@ int vg_try_dgrad_thin(const vg_conv_geom* g, const float* gy, const float* w, co
 
 extern "C" int vg_conv2d_dgrad(const vg_conv_geom* g, const float* gy, const float* w, const float* bias,
                                float* gx, void* stream) {
-  return vg_conv2d_dgrad_prec(g, gy, w, bias, gx, VG_PREC_F32, nullptr, 0, stream);
+  return vg_conv2d_dgrad_prec(g, gy, w, bias, gx, VG_PREC_F32, nullptr, 0, nullptr, nullptr, stream);
 }
 
 extern "C" int vg_conv2d_dgrad_prec(const vg_conv_geom* g, const float* gy, const float* w, const float* bias,
-                                    float* gx, int precision, void* workspace, size_t workspace_bytes, void* stream) {
+                                    float* gx, int precision, void* workspace, size_t workspace_bytes, const void* gy_planes,
+                                    const void* w_planes, void* stream) {
   if (int e = vg_check_geom(g, "vg_conv2d_dgrad")) return e;
   if (precision < VG_PREC_F32 || precision > VG_PREC_F32_SPLIT)
     return vg_fail(VG_ERR_INVALID, "vg_conv2d_dgrad: unknown precision %d", precision);
@@ -48,7 +49,7 @@ extern "C" int vg_conv2d_dgrad_prec(const vg_conv_geom* g, const float* gy, cons
     PgemmParams pp{};
     pp.g = p;
     if (int e = pgemm_prepare(pp, gy, (long long)g->N * g->Ho * g->Wo * g->Co, w, (long long)g->Co * g->kh * g->kw * g->Ci,
-                              3, workspace, workspace_bytes, (hipStream_t)stream, "vg_conv2d_dgrad"))
+                              3, workspace, workspace_bytes, (hipStream_t)stream, "vg_conv2d_dgrad", gy_planes, w_planes))
       return e;
     if (pgemm_launch<MODE_DGRAD, 3>(pp, bm, bn, grid, (hipStream_t)stream) != 0)
       return vg_fail(VG_ERR_INVALID, "vg_conv2d_dgrad: no plane kernel for tile %dx%d", bm, bn);

@@ -27,11 +27,12 @@ static int check_precision(int precision, const char* who) {
 
 extern "C" int vg_conv2d_fwd(const vg_conv_geom* g, const float* x, const float* w, const float* bias, float* y,
                              void* stream) {
-  return vg_conv2d_fwd_prec(g, x, w, bias, y, VG_PREC_F32, nullptr, 0, stream);
+  return vg_conv2d_fwd_prec(g, x, w, bias, y, VG_PREC_F32, nullptr, 0, nullptr, nullptr, stream);
 }
 
 extern "C" int vg_conv2d_fwd_prec(const vg_conv_geom* g, const float* x, const float* w, const float* bias,
-                                  float* y, int precision, void* workspace, size_t workspace_bytes, void* stream) {
+                                  float* y, int precision, void* workspace, size_t workspace_bytes, const void* x_planes,
+                                  const void* w_planes, void* stream) {
   if (int e = vg_check_geom(g, "vg_conv2d_fwd")) return e;
   if (int e = check_precision(precision, "vg_conv2d_fwd")) return e;
   VG_REQUIRE(x && w && y, "vg_conv2d_fwd: null tensor pointer");
@@ -57,7 +58,7 @@ extern "C" int vg_conv2d_fwd_prec(const vg_conv_geom* g, const float* x, const f
     PgemmParams pp{};
     pp.g = p;
     if (int e = pgemm_prepare(pp, x, (long long)g->N * g->H * g->W * g->Ci, w, (long long)g->Co * p.Ktot, 3, workspace,
-                              workspace_bytes, (hipStream_t)stream, "vg_conv2d_fwd"))
+                              workspace_bytes, (hipStream_t)stream, "vg_conv2d_fwd", x_planes, w_planes))
       return e;
     if (pgemm_launch<MODE_FWD, 3>(pp, bm, bn, grid, (hipStream_t)stream) != 0)
       return vg_fail(VG_ERR_INVALID, "vg_conv2d_fwd: no plane kernel for tile %dx%d", bm, bn);

@@ -65,6 +65,15 @@ int vg_split_planes(const float* in, long long elements, int np, void* planes, h
   return 0;
 }
 
+extern "C" size_t vg_split_planes_bytes(long long elements) { return elements > 0 ? vg_planes_bytes(elements, 3) : 0; }
+
+extern "C" int vg_split_planes_f32(const float* in, long long elements, void* planes, void* stream) {
+  VG_REQUIRE(in && planes && elements > 0 && ((uintptr_t)planes & 15) == 0, "vg_split_planes_f32: bad arguments");
+  vg_split_planes(in, elements, 3, planes, (hipStream_t)stream);
+  VG_CHECK_LAUNCH("vg_split_planes_f32");
+  return VG_OK;
+}
+
 // Which contractions the plane GEMM serves: 16-byte vectors of 8 bf16 along every contiguous index, and a tile
 // family of 64 / 128 columns. mode 0 fwd, 1 dgrad, 2 wgrad; the caller has already routed the thin and 1x1 special
 // cases elsewhere.

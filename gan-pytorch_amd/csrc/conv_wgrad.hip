@@ -106,14 +106,22 @@ extern "C" size_t vg_conv2d_prec_workspace_bytes(int mode, const vg_conv_geom* g
   return bytes;
 }
 
+// 1 when (mode, geometry) is served by the plane GEMM in the split mode, i.e. when pre-split operands are of use.
+extern "C" int vg_conv2d_split_applies(int mode, const vg_conv_geom* g) {
+  if (vg_check_geom(g, "vg_conv2d_split_applies") || mode < 0 || mode > 2) return 0;
+  if (mode == 2 && wgrad_plan(g).bn == 32) return 0;
+  return vg_planes_applicable(mode, g);
+}
+
 // Phase 1: the contraction. With more than one split the per-split slabs land in `workspace`, otherwise `gw` is final.
 extern "C" int vg_conv2d_wgrad_partial(const vg_conv_geom* g, const float* gy, const float* x, float* gw, void* workspace,
                                        size_t workspace_bytes, void* stream) {
-  return vg_conv2d_wgrad_partial_prec(g, gy, x, gw, workspace, workspace_bytes, VG_PREC_F32, stream);
+  return vg_conv2d_wgrad_partial_prec(g, gy, x, gw, workspace, workspace_bytes, VG_PREC_F32, nullptr, nullptr, stream);
 }
 
 extern "C" int vg_conv2d_wgrad_partial_prec(const vg_conv_geom* g, const float* gy, const float* x, float* gw,
-                                            void* workspace, size_t workspace_bytes, int precision, void* stream) {
+                                            void* workspace, size_t workspace_bytes, int precision, const void* gy_planes,
+                                            const void* x_planes, void* stream) {
   if (int e = vg_check_geom(g, "vg_conv2d_wgrad")) return e;
   if (precision < VG_PREC_F32 || precision > VG_PREC_F32_SPLIT)
     return vg_fail(VG_ERR_INVALID, "vg_conv2d_wgrad: unknown precision %d", precision);
@@ -143,7 +151,8 @@ extern "C" int vg_conv2d_wgrad_partial_prec(const vg_conv_geom* g, const float* 
     const size_t skip = slab_bytes(pl);
     if (workspace_bytes < skip) return vg_fail(VG_ERR_WORKSPACE, "vg_conv2d_wgrad: workspace too small for split mode");
     if (int e = pgemm_prepare(pp, gy, (long long)g->N * g->Ho * g->Wo * g->Co, x, (long long)g->N * g->H * g->W * g->Ci, 3,
-                              (char*)workspace + skip, workspace_bytes - skip, (hipStream_t)stream, "vg_conv2d_wgrad"))
+                              (char*)workspace + skip, workspace_bytes - skip, (hipStream_t)stream, "vg_conv2d_wgrad", gy_planes,
+                              x_planes))
       return e;
     if (pgemm_launch<MODE_WGRAD, 3>(pp, pl.bm, pl.bn, grid, (hipStream_t)stream) != 0)
       return vg_fail(VG_ERR_INVALID, "vg_conv2d_wgrad: no plane kernel for tile %dx%d", pl.bm, pl.bn);

@@ -467,17 +467,29 @@ int vg_planes_applicable(int mode, const vg_conv_geom* g);
 size_t vg_planes_operand_bytes(int mode, const vg_conv_geom* g, int np);
 
 // Splits both operands into `workspace` (A's planes first) and fills the plane fields of `pp`.
+// An operand whose planes the caller already holds (a_planes / b_planes, as vg_split_planes wrote them) is taken
+// from there.
 static inline int pgemm_prepare(PgemmParams& pp, const float* A, long long a_elems, const float* B, long long b_elems,
-                                int np, void* workspace, size_t workspace_bytes, hipStream_t st, const char* who) {
-  const size_t need = vg_planes_bytes(a_elems, np) + vg_planes_bytes(b_elems, np);
-  if (!workspace || workspace_bytes < need || ((uintptr_t)workspace & 255) != 0)
+                                int np, void* workspace, size_t workspace_bytes, hipStream_t st, const char* who,
+                                const void* a_planes = nullptr, const void* b_planes = nullptr) {
+  const size_t need = (a_planes ? 0 : vg_planes_bytes(a_elems, np)) + (b_planes ? 0 : vg_planes_bytes(b_elems, np));
+  if (need > 0 && (!workspace || workspace_bytes < need || ((uintptr_t)workspace & 255) != 0))
     return vg_fail(VG_ERR_WORKSPACE, "%s: split mode needs a 256-byte aligned workspace of %zu bytes, got %zu", who, need,
                    workspace_bytes);
+  if (((uintptr_t)a_planes & 15) != 0 || ((uintptr_t)b_planes & 15) != 0)
+    return vg_fail(VG_ERR_INVALID, "%s: operand planes must be 16-byte aligned", who);
   char* ws = (char*)workspace;
-  vg_split_planes(A, a_elems, np, ws, st);
-  vg_split_planes(B, b_elems, np, ws + vg_planes_bytes(a_elems, np), st);
-  pp.Ap = (const __bf16*)ws;
-  pp.Bp = (const __bf16*)(ws + vg_planes_bytes(a_elems, np));
+  if (!a_planes) {
+    vg_split_planes(A, a_elems, np, ws, st);
+    a_planes = ws;
+    ws += vg_planes_bytes(a_elems, np);
+  }
+  if (!b_planes) {
+    vg_split_planes(B, b_elems, np, ws, st);
+    b_planes = ws;
+  }
+  pp.Ap = (const __bf16*)a_planes;
+  pp.Bp = (const __bf16*)b_planes;
   pp.a_plane = vg_plane_stride(a_elems);
   pp.b_plane = vg_plane_stride(b_elems);
   return 0;

@@ -239,6 +239,49 @@ def _conv_workspace(mode, g, device):
     return nbytes, ctypes.c_void_p(workspace(nbytes, device).data_ptr())
 
 
+class _PlaneCache:
+    """Split-mode operands (three bf16 terms per value) kept for the rest of a training iteration, so a tensor that
+    feeds several contractions - an activation its forward convolution and its weight gradient, a back-propagated
+    gradient the input and the weight gradient, a weight every pass through its layer - is split once. An entry
+    keeps its source tensor alive (so the address cannot be handed to another tensor) and is valid for one tensor
+    version; everything is dropped when parameters change (optimizer step, clip) and at the iteration's boundaries.
+    The cache is only switched on inside the training iteration: a captured HIP graph then contains exactly the
+    splits an eager iteration runs, and never refers to planes made outside itself."""
+
+    def __init__(self):
+        self.active = False
+        self.entries = {}
+
+    def begin(self):
+        self.entries.clear()
+        self.active = True
+
+    def end(self):
+        self.entries.clear()
+        self.active = False
+
+    def clear(self):
+        self.entries.clear()
+
+    def pointer(self, mode, g, t):
+        """Device pointer to the planes of `t` (already in kernel memory order), or None when the library should split
+        the operand itself."""
+        if not self.active or _precision != 2 or not _hip.load().vg_conv2d_split_applies(mode, ctypes.byref(g.c)):
+            return None
+        key = t.data_ptr()
+        hit = self.entries.get(key)
+        if hit is not None and hit[0]._version == hit[1] and hit[0].numel() == t.numel():
+            return ctypes.c_void_p(hit[2].data_ptr())
+        n = t.numel()
+        planes = torch.empty(_hip.load().vg_split_planes_bytes(n), dtype=torch.uint8, device=t.device)
+        call("vg_split_planes_f32", _ptr(t), ctypes.c_longlong(n), ctypes.c_void_p(planes.data_ptr()), _stream())
+        self.entries[key] = (t, t._version, planes)
+        return ctypes.c_void_p(planes.data_ptr())
+
+
+plane_cache = _PlaneCache()
+
+
 def raw_conv_fwd(g, x, w, bias):
     x, w = to_nhwc(x), _weight_mem(w)
     _check_shape(x, g.x_shape(), "conv input")
@@ -246,8 +289,9 @@ def raw_conv_fwd(g, x, w, bias):
         raise _hip.HipError("weight has %d elements, geometry expects %d" % (w.numel(), g.w_numel()))
     y = _new_act(g.N, g.Co, g.Ho, g.Wo, x, g.flat)
     nbytes, wsp = _conv_workspace(0, g, x.device)
+    xp, wp = plane_cache.pointer(0, g, x), plane_cache.pointer(0, g, w)
     _launch_conv(0, g, lambda: call("vg_conv2d_fwd_prec", ctypes.byref(g.c), _ptr(x), _ptr(w), _ptr(bias), _ptr(y),
-                                    _precision, wsp, c_size_t(nbytes), _stream()))
+                                    _precision, wsp, c_size_t(nbytes), xp, wp, _stream()))
     return y
 
 
@@ -258,8 +302,9 @@ def raw_conv_dgrad(g, gy, w, bias):
         raise _hip.HipError("weight has %d elements, geometry expects %d" % (w.numel(), g.w_numel()))
     gx = _new_act(g.N, g.Ci, g.H, g.W, gy, g.flat)
     nbytes, wsp = _conv_workspace(1, g, gy.device)
+    gp, wp = plane_cache.pointer(1, g, gy), plane_cache.pointer(1, g, w)
     _launch_conv(1, g, lambda: call("vg_conv2d_dgrad_prec", ctypes.byref(g.c), _ptr(gy), _ptr(w), _ptr(bias), _ptr(gx),
-                                    _precision, wsp, c_size_t(nbytes), _stream()))
+                                    _precision, wsp, c_size_t(nbytes), gp, wp, _stream()))
     return gx
 
 
@@ -274,8 +319,9 @@ def raw_conv_wgrad(g, gy, x, w_shape):
     if gw.numel() != g.w_numel():
         raise _hip.HipError("weight gradient shape %s does not match the geometry" % (tuple(w_shape),))
     nbytes, wsp = _conv_workspace(2, g, x.device)
+    gp, xp = plane_cache.pointer(2, g, gy), plane_cache.pointer(2, g, x)
     _launch_conv(2, g, lambda: call("vg_conv2d_wgrad_partial_prec", ctypes.byref(g.c), _ptr(gy), _ptr(x), _ptr(gw), wsp,
-                                    c_size_t(nbytes), _precision, _stream()))
+                                    c_size_t(nbytes), _precision, gp, xp, _stream()))
     if _hip.load().vg_conv2d_wgrad_workspace_bytes(ctypes.byref(g.c)):
         call("vg_conv2d_wgrad_reduce", ctypes.byref(g.c), _ptr(gw), wsp, _stream())
     return gw

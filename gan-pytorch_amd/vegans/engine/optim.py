@@ -49,6 +49,8 @@ def _grad_mem(p):
 
 def fused_step(optimizer, grad_scale=1.0, clamp=None):
     """One optimizer step for every parameter that has a gradient. `clamp=(lo, hi)` clamps after the update."""
+    from . import ops
+    ops.plane_cache.clear()      # the kernels below rewrite parameters in place, behind torch's version counters
     lo, hi = clamp if clamp is not None else _NO_CLAMP
     kind = type(optimizer)
     if kind is torch.optim.RMSprop:

@@ -319,14 +319,18 @@ class AbstractGenerativeModel(ABC):
         graph.run_step(self, self._train_on_batch_body, (X, Z))
 
     def _train_on_batch_body(self, X, Z):
-        for name in self.neural_nets:
-            for _ in range(self.steps[name]):
-                self._losses = {}
-                with self._training_only(name):
-                    self.calculate_losses(X_batch=X, Z_batch=Z, who=name)
-                    self._zero_grad(who=name)
-                    self._backward(who=name)
-                self._step(who=name)
+        ops.plane_cache.begin()
+        try:
+            for name in self.neural_nets:
+                for _ in range(self.steps[name]):
+                    self._losses = {}
+                    with self._training_only(name):
+                        self.calculate_losses(X_batch=X, Z_batch=Z, who=name)
+                        self._zero_grad(who=name)
+                        self._backward(who=name)
+                    self._step(who=name)
+        finally:
+            ops.plane_cache.end()
 
     def _draw_latent(self, n_local, dp):
         """One latent batch per data batch (AbstractGenerativeModel.py:320). The training loop never needs
@@ -654,14 +658,18 @@ class AbstractConditionalGenerativeModel(AbstractGenerativeModel):
         graph.run_step(self, self._train_on_batch_body, (X, y, Z))
 
     def _train_on_batch_body(self, X, y, Z):
-        for name in self.neural_nets:
-            for _ in range(self.steps[name]):
-                self._losses = {}
-                with self._training_only(name):
-                    self.calculate_losses(X_batch=X, Z_batch=Z, y_batch=y, who=name)
-                    self._zero_grad(who=name)
-                    self._backward(who=name)
-                self._step(who=name)
+        ops.plane_cache.begin()
+        try:
+            for name in self.neural_nets:
+                for _ in range(self.steps[name]):
+                    self._losses = {}
+                    with self._training_only(name):
+                        self.calculate_losses(X_batch=X, Z_batch=Z, y_batch=y, who=name)
+                        self._zero_grad(who=name)
+                        self._backward(who=name)
+                    self._step(who=name)
+        finally:
+            ops.plane_cache.end()
 
     def _log_losses(self, X_batch, Z_batch, y_batch, mode):
         self._losses = {}

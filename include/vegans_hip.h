@@ -92,12 +92,23 @@ int vg_conv2d_wgrad_reduce(const vg_conv_geom* g, float* gw, const void* workspa
  * vg_conv2d_wgrad_reduce takes the same pointer. */
 enum { VG_PREC_F32 = 0, VG_PREC_BF16 = 1, VG_PREC_F32_SPLIT = 2 };
 size_t vg_conv2d_prec_workspace_bytes(int mode, const vg_conv_geom* g, int precision);   /* mode 0 fwd, 1 dgrad, 2 wgrad */
+/* The `*_planes` arguments (nullable) hand over an operand that the caller has already split with vg_split_planes_f32,
+ * e.g. an activation that feeds both a forward contraction and, later, a weight gradient; they are only read in the
+ * split mode, for shapes vg_conv2d_split_applies reports as served by it. */
 int vg_conv2d_fwd_prec(const vg_conv_geom* g, const float* x, const float* w, const float* bias, float* y,
-                       int precision, void* workspace, size_t workspace_bytes, void* stream);
+                       int precision, void* workspace, size_t workspace_bytes, const void* x_planes,
+                       const void* w_planes, void* stream);
 int vg_conv2d_dgrad_prec(const vg_conv_geom* g, const float* gy, const float* w, const float* bias, float* gx,
-                         int precision, void* workspace, size_t workspace_bytes, void* stream);
+                         int precision, void* workspace, size_t workspace_bytes, const void* gy_planes,
+                         const void* w_planes, void* stream);
 int vg_conv2d_wgrad_partial_prec(const vg_conv_geom* g, const float* gy, const float* x, float* gw, void* workspace,
-                                 size_t workspace_bytes, int precision, void* stream);
+                                 size_t workspace_bytes, int precision, const void* gy_planes, const void* x_planes,
+                                 void* stream);
+/* The three bf16 terms of `elements` f32 values, written one plane after the other into `planes`
+ * (vg_split_planes_bytes(elements) bytes, 16-byte aligned); and whether the split mode serves (mode, geometry). */
+size_t vg_split_planes_bytes(long long elements);
+int vg_split_planes_f32(const float* in, long long elements, void* planes, void* stream);
+int vg_conv2d_split_applies(int mode, const vg_conv_geom* g);
 
 /* Name of the kernel template instance the call for (mode, geometry) dispatches to (mode 0 fwd, 1 dgrad, 2 wgrad;
  * 16-byte aligned tensors assumed), as a kernel trace prints it.  No counterpart in the reference: it exists so a
