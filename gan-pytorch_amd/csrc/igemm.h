@@ -88,15 +88,27 @@ __global__ void __launch_bounds__(NW * 64) igemm_kernel(const IgemmParams p) {
   const int r = lane & 31, h = lane >> 5;
   const int wm = wid / WAVES_N, wn = wid % WAVES_N;
 
-  // XCD-aware tile order: blocks b and b+8 share an L2, so give each XCD a contiguous run of tiles
-  // (bijective for any grid size).
-  int mt, nt;
+  // XCD-aware block order. Workgroups are dealt to the 8 XCDs round-robin in dispatch order (x fastest, then z), and
+  // each XCD has its own L2. Every XCD is given a contiguous run of the logical order "z-major, then tile" (bijective
+  // for any grid size): for the weight gradient that is whole split-K chunks, whose tiles all read the same pixels, so
+  // the activations stream through one L2 once instead of through all eight; for the forward mode a run of row tiles
+  // with all their column tiles; for the input gradient "tile-major, then class".
+  int mt, nt, zz;
   {
-    const int bid = blockIdx.x, nblk = gridDim.x;
-    const int xcd = bid & 7, q = nblk >> 3, rem = nblk & 7;
-    const int id = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + (bid >> 3);
-    mt = id / p.ntiles;
-    nt = id - mt * p.ntiles;
+    const int tiles = gridDim.x, nblk = gridDim.x * gridDim.z;
+    const int lin = blockIdx.x + gridDim.x * blockIdx.z;
+    const int xcd = lin & 7, q = nblk >> 3, rem = nblk & 7;
+    const int id = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + (lin >> 3);
+    int t;
+    if constexpr (MODE == MODE_DGRAD) {   // the parity classes of one row tile read the same gradient pixels: keep them together
+      t = id / (int)gridDim.z;
+      zz = id - t * (int)gridDim.z;
+    } else {
+      zz = id / tiles;
+      t = id - zz * tiles;
+    }
+    mt = t / p.ntiles;
+    nt = t - mt * p.ntiles;
   }
   const int m0 = mt * BM, n0 = nt * BN;
 
@@ -106,8 +118,8 @@ __global__ void __launch_bounds__(NW * 64) igemm_kernel(const IgemmParams p) {
   // dgrad parity class
   int cls_h = 0, cls_w = 0, off_h = 0, off_w = 0, Hc = 0, Wc = 0, nth = 0, ntw = 0, base_h = 0, base_w = 0;
   if constexpr (MODE == MODE_DGRAD) {
-    cls_h = blockIdx.z / p.sw;
-    cls_w = blockIdx.z - cls_h * p.sw;
+    cls_h = zz / p.sw;
+    cls_w = zz - cls_h * p.sw;
     off_h = ((cls_h - p.ph) % p.sh + p.sh) % p.sh;
     off_w = ((cls_w - p.pw) % p.sw + p.sw) % p.sw;
     Hc = off_h < p.H ? (p.H - off_h + p.sh - 1) / p.sh : 0;
@@ -121,7 +133,7 @@ __global__ void __launch_bounds__(NW * 64) igemm_kernel(const IgemmParams p) {
     kend = Ktot;
     if (m0 >= M) return;  // block-uniform
   } else if constexpr (MODE == MODE_WGRAD) {
-    kbeg = blockIdx.z * p.kchunk;
+    kbeg = zz * p.kchunk;
     kend = min(kbeg + p.kchunk, p.Ktot);
   } else {
     ntw = p.KW;
@@ -609,7 +621,7 @@ __global__ void __launch_bounds__(NW * 64) igemm_kernel(const IgemmParams p) {
 
   // ---- epilogue: lane holds column (lane&31) and rows (e&3)+8*(e>>2)+4*(lane>>5) of each 32x32 tile ----
   float* outp = p.out;
-  if constexpr (MODE == MODE_WGRAD) outp += (size_t)blockIdx.z * p.slab_stride;
+  if constexpr (MODE == MODE_WGRAD) outp += (size_t)zz * p.slab_stride;
 #pragma unroll
   for (int mi = 0; mi < TM; ++mi) {
 #pragma unroll

@@ -64,8 +64,14 @@ __global__ void __launch_bounds__(NW * 64) pgemm_kernel(const PgemmParams pp) {
     const int lin = blockIdx.x + gridDim.x * blockIdx.z;
     const int xcd = lin & 7, q = nblk >> 3, rem = nblk & 7;
     const int id = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + (lin >> 3);
-    zz = id / tiles;
-    const int t = id - zz * tiles;
+    int t;
+    if constexpr (MODE == MODE_DGRAD) {   // the parity classes of one row tile read the same gradient pixels: keep them together
+      t = id / (int)gridDim.z;
+      zz = id - t * (int)gridDim.z;
+    } else {
+      zz = id / tiles;
+      t = id - zz * tiles;
+    }
     mt = t / p.ntiles;
     nt = t - mt * p.ntiles;
   }
