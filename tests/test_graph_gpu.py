@@ -20,13 +20,13 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-def _model(algo, steps=None, seed=4, **extra):
+def _model(algo, steps=None, seed=4, width=8, **extra):
     import bench_configs as cfg
     import vegans.GAN as gan
     torch.manual_seed(seed)
     np.random.seed(seed)
-    G = cfg.seeded_init(cfg.dcgan_generator(nz=16, ngf=8, nc=3, size=16), 1, 0.08)
-    D = cfg.seeded_init(cfg.dcgan_critic(ndf=8, nc=3, size=16, sigmoid=algo in ("LSGAN", "VanillaGAN")), 2, 0.08)
+    G = cfg.seeded_init(cfg.dcgan_generator(nz=16, ngf=width, nc=3, size=16), 1, 0.08)
+    D = cfg.seeded_init(cfg.dcgan_critic(ndf=width, nc=3, size=16, sigmoid=algo in ("LSGAN", "VanillaGAN")), 2, 0.08)
     okw = {"Generator": {"lr": 1e-3}, "Adversariat": {"lr": 5e-4}}
     m = getattr(gan, algo)(G, D, x_dim=(3, 16, 16), z_dim=(16, 1, 1), optim_kwargs=okw, folder=None,
                            fixed_noise_size=4, **extra)
@@ -109,6 +109,39 @@ def test_replayed_step_matches_eager(gpu, algo, steps, extra, exact):
             _same(s0[k].float(), s1[k].float(), exact or ".opt" in k and k.endswith("step"), k)
         else:
             assert s0[k] == s1[k], k
+
+
+def test_replayed_step_matches_eager_in_split_mode(gpu):
+    """The split mode keeps the bf16 terms of operands for the rest of an iteration (ops.plane_cache); a captured
+    graph must contain exactly the splits the eager iteration runs and read no planes made outside itself: replayed
+    and eager iterations of the clipped Wasserstein GAN agree bit for bit, as in f32. Width 32 puts several layers on
+    the plane kernels."""
+    import bench_configs as cfg
+    from vegans.engine import ops
+    iters, B = 6, 8
+    data = cfg.synthetic_images(B * iters, (3, 16, 16), seed=8)
+    g = torch.Generator().manual_seed(12)
+    zs = [torch.randn(B, 16, 1, 1, generator=g) for _ in range(iters)]
+    previous = ops.set_matmul_precision("fp32_split")
+    try:
+        results = []
+        for use_graph in (False, True):
+            m = _model("WassersteinGAN", {"Adversariat": 2}, width=32, clip_val=0.02)
+            batches = [m._to_device(data[i * B:(i + 1) * B]) for i in range(iters)]
+            losses, next_draw, entries = _run(m, batches, [z.to("cuda") for z in zs], use_graph)
+            if use_graph:
+                assert len(entries) == 1 and entries[0].graph is not None and not entries[0].failed
+            results.append((losses, _state(m)))
+            assert not ops.plane_cache.active and not ops.plane_cache.entries
+    finally:
+        ops.set_matmul_precision(previous)
+    (l0, s0), (l1, s1) = results
+    for i, (a, b) in enumerate(zip(l0, l1)):
+        for k in a:
+            _same(a[k].reshape(1), b[k].reshape(1), True, "iteration %d loss %s" % (i, k))
+    for k in s0:
+        if isinstance(s0[k], torch.Tensor):
+            _same(s0[k].float(), s1[k].float(), True, k)
 
 
 def test_graph_follows_hyperparameter_and_shape_changes(gpu):
