@@ -27,6 +27,7 @@ extern "C" int vg_conv2d_dgrad_prec(const vg_conv_geom* g, const float* gy, cons
   if (int r = vg_try_dgrad_thin(g, gy, w, bias, gx, (hipStream_t)stream)) return r < 0 ? r : VG_OK;
 
   if (precision == VG_PREC_F32_SPLIT && !vg_planes_applicable(1, g)) precision = VG_PREC_F32;
+  const bool planes = pgemm_serves(precision, 1, g);
   IgemmParams p{};
   p.A = gy; p.B = w; p.bias = bias; p.out = gx;
   p.N = g->N; p.H = g->H; p.W = g->W; p.Ci = g->Ci; p.Co = g->Co; p.KH = g->kh; p.KW = g->kw;
@@ -40,18 +41,20 @@ extern "C" int vg_conv2d_dgrad_prec(const vg_conv_geom* g, const float* gy, cons
   p.Ktot = 0;  // per class, derived in the kernel
   const int bn = igemm_pick_bn(p.Ncols, precision);
   p.ntiles = (p.Ncols + bn - 1) / bn;
-  const int bm = igemm_pick_bm(p.M, p.ntiles, g->sh * g->sw, bn, precision);
+  const int bm = igemm_pick_bm(p.M, p.ntiles, g->sh * g->sw, bn, planes ? PREC_SPLIT : precision);
   p.mtiles = (p.M + bm - 1) / bm;
   const int va = (g->Co % 4 == 0 && vg_aligned16(gy)) ? 4 : 1;
   const int vb = (g->Ci % 4 == 0 && vg_aligned16(w)) ? 4 : 1;
   dim3 grid((unsigned)(p.mtiles * p.ntiles), 1, (unsigned)(g->sh * g->sw));
-  if (precision == VG_PREC_F32_SPLIT) {
+  if (planes) {
+    const int np = vg_planes_of(precision);
     PgemmParams pp{};
     pp.g = p;
     if (int e = pgemm_prepare(pp, gy, (long long)g->N * g->Ho * g->Wo * g->Co, w, (long long)g->Co * g->kh * g->kw * g->Ci,
-                              3, workspace, workspace_bytes, (hipStream_t)stream, "vg_conv2d_dgrad", gy_planes, w_planes))
+                              np, workspace, workspace_bytes, (hipStream_t)stream, "vg_conv2d_dgrad", gy_planes, w_planes))
       return e;
-    if (pgemm_launch<MODE_DGRAD, 3>(pp, bm, bn, grid, (hipStream_t)stream) != 0)
+    if ((np == 3 ? pgemm_launch<MODE_DGRAD, 3>(pp, bm, bn, grid, (hipStream_t)stream)
+                 : pgemm_launch<MODE_DGRAD, 1>(pp, bm, bn, grid, (hipStream_t)stream)) != 0)
       return vg_fail(VG_ERR_INVALID, "vg_conv2d_dgrad: no plane kernel for tile %dx%d", bm, bn);
     VG_CHECK_LAUNCH("vg_conv2d_dgrad(planes)");
     return VG_OK;

@@ -38,6 +38,7 @@ extern "C" int vg_conv2d_fwd_prec(const vg_conv_geom* g, const float* x, const f
   VG_REQUIRE(x && w && y, "vg_conv2d_fwd: null tensor pointer");
   if (int r = vg_try_fwd_thin(g, x, w, bias, y, (hipStream_t)stream)) return r < 0 ? r : VG_OK;
   if (precision == VG_PREC_F32_SPLIT && !vg_planes_applicable(0, g)) precision = VG_PREC_F32;
+  const bool planes = pgemm_serves(precision, 0, g);
   IgemmParams p{};
   p.A = x; p.B = w; p.bias = bias; p.out = y;
   p.N = g->N; p.H = g->H; p.W = g->W; p.Ci = g->Ci; p.Co = g->Co; p.KH = g->kh; p.KW = g->kw;
@@ -49,18 +50,20 @@ extern "C" int vg_conv2d_fwd_prec(const vg_conv_geom* g, const float* x, const f
   p.bias_mod = g->Co;
   const int bn = igemm_pick_bn(p.Ncols, precision);
   p.ntiles = (p.Ncols + bn - 1) / bn;
-  const int bm = igemm_pick_bm(p.M, p.ntiles, 1, bn, precision);
+  const int bm = igemm_pick_bm(p.M, p.ntiles, 1, bn, planes ? PREC_SPLIT : precision);
   p.mtiles = (p.M + bm - 1) / bm;
   const int va = (g->Ci % 4 == 0 && vg_aligned16(x)) ? 4 : 1;
   const int vb = (p.Ktot % 4 == 0 && vg_aligned16(w)) ? 4 : 1;
   dim3 grid((unsigned)(p.mtiles * p.ntiles), 1, 1);
-  if (precision == VG_PREC_F32_SPLIT) {
+  if (planes) {
+    const int np = vg_planes_of(precision);
     PgemmParams pp{};
     pp.g = p;
-    if (int e = pgemm_prepare(pp, x, (long long)g->N * g->H * g->W * g->Ci, w, (long long)g->Co * p.Ktot, 3, workspace,
+    if (int e = pgemm_prepare(pp, x, (long long)g->N * g->H * g->W * g->Ci, w, (long long)g->Co * p.Ktot, np, workspace,
                               workspace_bytes, (hipStream_t)stream, "vg_conv2d_fwd", x_planes, w_planes))
       return e;
-    if (pgemm_launch<MODE_FWD, 3>(pp, bm, bn, grid, (hipStream_t)stream) != 0)
+    if ((np == 3 ? pgemm_launch<MODE_FWD, 3>(pp, bm, bn, grid, (hipStream_t)stream)
+                 : pgemm_launch<MODE_FWD, 1>(pp, bm, bn, grid, (hipStream_t)stream)) != 0)
       return vg_fail(VG_ERR_INVALID, "vg_conv2d_fwd: no plane kernel for tile %dx%d", bm, bn);
     VG_CHECK_LAUNCH("vg_conv2d_fwd(planes)");
     return VG_OK;

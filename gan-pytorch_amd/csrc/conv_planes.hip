@@ -65,11 +65,24 @@ int vg_split_planes(const float* in, long long elements, int np, void* planes, h
   return 0;
 }
 
-extern "C" size_t vg_split_planes_bytes(long long elements) { return elements > 0 ? vg_planes_bytes(elements, 3) : 0; }
+// bf16 terms per value under a precision setting: 3 in the split mode, 1 (the rounded value) in the bf16 mode
+int vg_planes_of(int precision) { return precision == VG_PREC_F32_SPLIT ? 3 : 1; }
 
-extern "C" int vg_split_planes_f32(const float* in, long long elements, void* planes, void* stream) {
-  VG_REQUIRE(in && planes && elements > 0 && ((uintptr_t)planes & 15) == 0, "vg_split_planes_f32: bad arguments");
-  vg_split_planes(in, elements, 3, planes, (hipStream_t)stream);
+// whether the bf16 mode also runs on pre-converted operands (default) or converts inside the contraction's loader
+bool vg_bf16_uses_planes() {
+  static const bool on = !(getenv("VG_BF16_PLANES") && atoi(getenv("VG_BF16_PLANES")) == 0);
+  return on;
+}
+
+extern "C" size_t vg_split_planes_bytes(long long elements, int precision) {
+  return elements > 0 && precision != VG_PREC_F32 ? vg_planes_bytes(elements, vg_planes_of(precision)) : 0;
+}
+
+extern "C" int vg_split_planes_f32(const float* in, long long elements, int precision, void* planes, void* stream) {
+  VG_REQUIRE(in && planes && elements > 0 && ((uintptr_t)planes & 15) == 0 &&
+                 (precision == VG_PREC_BF16 || precision == VG_PREC_F32_SPLIT),
+             "vg_split_planes_f32: bad arguments");
+  vg_split_planes(in, elements, vg_planes_of(precision), planes, (hipStream_t)stream);
   VG_CHECK_LAUNCH("vg_split_planes_f32");
   return VG_OK;
 }

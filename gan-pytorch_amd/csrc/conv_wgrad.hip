@@ -102,15 +102,15 @@ static size_t slab_bytes(const WgradPlan& pl) {
 extern "C" size_t vg_conv2d_prec_workspace_bytes(int mode, const vg_conv_geom* g, int precision) {
   if (vg_check_geom(g, "vg_conv2d_prec_workspace_bytes") || mode < 0 || mode > 2) return 0;
   size_t bytes = mode == 2 ? slab_bytes(wgrad_plan(g)) : 0;
-  if (precision == VG_PREC_F32_SPLIT && vg_planes_applicable(mode, g)) bytes += vg_planes_operand_bytes(mode, g, 3);
+  if (pgemm_serves(precision, mode, g)) bytes += vg_planes_operand_bytes(mode, g, vg_planes_of(precision));
   return bytes;
 }
 
-// 1 when (mode, geometry) is served by the plane GEMM in the split mode, i.e. when pre-split operands are of use.
-extern "C" int vg_conv2d_split_applies(int mode, const vg_conv_geom* g) {
+// 1 when (mode, geometry) runs on pre-converted operands under `precision`, i.e. when operand planes are of use.
+extern "C" int vg_conv2d_split_applies(int mode, const vg_conv_geom* g, int precision) {
   if (vg_check_geom(g, "vg_conv2d_split_applies") || mode < 0 || mode > 2) return 0;
   if (mode == 2 && wgrad_plan(g).bn == 32) return 0;
-  return vg_planes_applicable(mode, g);
+  return pgemm_serves(precision, mode, g) ? 1 : 0;
 }
 
 // Phase 1: the contraction. With more than one split the per-split slabs land in `workspace`, otherwise `gw` is final.
@@ -145,16 +145,18 @@ extern "C" int vg_conv2d_wgrad_partial_prec(const vg_conv_geom* g, const float* 
   const int va = (g->Co % 4 == 0 && vg_aligned16(gy)) ? 4 : 1;
   const int vb = (g->Ci % 4 == 0 && vg_aligned16(x)) ? 4 : 1;
   dim3 grid((unsigned)(pl.mtiles * pl.ntiles), 1, (unsigned)pl.nsplit);
-  if (precision == VG_PREC_F32_SPLIT && vg_planes_applicable(2, g) && pl.bn != 32) {
+  if (pgemm_serves(precision, 2, g) && pl.bn != 32) {
+    const int np = vg_planes_of(precision);
     PgemmParams pp{};
     pp.g = p;
     const size_t skip = slab_bytes(pl);
     if (workspace_bytes < skip) return vg_fail(VG_ERR_WORKSPACE, "vg_conv2d_wgrad: workspace too small for split mode");
-    if (int e = pgemm_prepare(pp, gy, (long long)g->N * g->Ho * g->Wo * g->Co, x, (long long)g->N * g->H * g->W * g->Ci, 3,
+    if (int e = pgemm_prepare(pp, gy, (long long)g->N * g->Ho * g->Wo * g->Co, x, (long long)g->N * g->H * g->W * g->Ci, np,
                               (char*)workspace + skip, workspace_bytes - skip, (hipStream_t)stream, "vg_conv2d_wgrad", gy_planes,
                               x_planes))
       return e;
-    if (pgemm_launch<MODE_WGRAD, 3>(pp, pl.bm, pl.bn, grid, (hipStream_t)stream) != 0)
+    if ((np == 3 ? pgemm_launch<MODE_WGRAD, 3>(pp, pl.bm, pl.bn, grid, (hipStream_t)stream)
+                 : pgemm_launch<MODE_WGRAD, 1>(pp, pl.bm, pl.bn, grid, (hipStream_t)stream)) != 0)
       return vg_fail(VG_ERR_INVALID, "vg_conv2d_wgrad: no plane kernel for tile %dx%d", pl.bm, pl.bn);
     VG_CHECK_LAUNCH("vg_conv2d_wgrad(planes)");
     return VG_OK;

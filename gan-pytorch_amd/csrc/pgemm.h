@@ -470,6 +470,14 @@ size_t vg_planes_bytes(long long elements, int np);   // workspace bytes for the
 int vg_split_planes(const float* in, long long elements, int np, void* planes, hipStream_t st);
 long long vg_plane_stride(long long elements);
 int vg_planes_applicable(int mode, const vg_conv_geom* g);
+int vg_planes_of(int precision);
+bool vg_bf16_uses_planes();
+
+// true when this precision runs (mode, g) on pre-converted operands
+static inline bool pgemm_serves(int precision, int mode, const vg_conv_geom* g) {
+  if (precision == VG_PREC_F32 || !vg_planes_applicable(mode, g)) return false;
+  return precision == VG_PREC_F32_SPLIT || vg_bf16_uses_planes();
+}
 size_t vg_planes_operand_bytes(int mode, const vg_conv_geom* g, int np);
 
 // Splits both operands into `workspace` (A's planes first) and fills the plane fields of `pp`.

@@ -59,9 +59,9 @@ SIGNATURES = {
     "vg_conv2d_fwd_prec": (c_int, [_G, _P, _P, _P, _P, c_int, _P, c_size_t, _P, _P, _P]),
     "vg_conv2d_dgrad_prec": (c_int, [_G, _P, _P, _P, _P, c_int, _P, c_size_t, _P, _P, _P]),
     "vg_conv2d_wgrad_partial_prec": (c_int, [_G, _P, _P, _P, _P, c_size_t, c_int, _P, _P, _P]),
-    "vg_split_planes_bytes": (c_size_t, [ctypes.c_longlong]),
-    "vg_split_planes_f32": (c_int, [_P, ctypes.c_longlong, _P, _P]),
-    "vg_conv2d_split_applies": (c_int, [c_int, _G]),
+    "vg_split_planes_bytes": (c_size_t, [ctypes.c_longlong, c_int]),
+    "vg_split_planes_f32": (c_int, [_P, ctypes.c_longlong, c_int, _P, _P]),
+    "vg_conv2d_split_applies": (c_int, [c_int, _G, c_int]),
     "vg_maxpool2d_fwd": (c_int, [POINTER(ConvGeom), _P, _P, _P, _P]),
     "vg_maxpool2d_bwd": (c_int, [POINTER(ConvGeom), _P, _P, _P, _P]),
     "vg_maxpool2d_pick": (c_int, [POINTER(ConvGeom), _P, _P, _P, _P]),

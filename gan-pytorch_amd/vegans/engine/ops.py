@@ -240,7 +240,7 @@ def _conv_workspace(mode, g, device):
 
 
 class _PlaneCache:
-    """Split-mode operands (three bf16 terms per value) kept for the rest of a training iteration, so a tensor that
+    """Split-mode and bf16-mode operands (their bf16 terms) kept for the rest of a training iteration, so a tensor that
     feeds several contractions - an activation its forward convolution and its weight gradient, a back-propagated
     gradient the input and the weight gradient, a weight every pass through its layer - is split once. An entry
     keeps its source tensor alive (so the address cannot be handed to another tensor) and is valid for one tensor
@@ -266,15 +266,17 @@ class _PlaneCache:
     def pointer(self, mode, g, t):
         """Device pointer to the planes of `t` (already in kernel memory order), or None when the library should split
         the operand itself."""
-        if not self.active or _precision != 2 or not _hip.load().vg_conv2d_split_applies(mode, ctypes.byref(g.c)):
+        if not self.active or _precision == 0 or not _hip.load().vg_conv2d_split_applies(mode, ctypes.byref(g.c),
+                                                                                         _precision):
             return None
         key = t.data_ptr()
         hit = self.entries.get(key)
         if hit is not None and hit[0]._version == hit[1] and hit[0].numel() == t.numel():
             return ctypes.c_void_p(hit[2].data_ptr())
         n = t.numel()
-        planes = torch.empty(_hip.load().vg_split_planes_bytes(n), dtype=torch.uint8, device=t.device)
-        call("vg_split_planes_f32", _ptr(t), ctypes.c_longlong(n), ctypes.c_void_p(planes.data_ptr()), _stream())
+        planes = torch.empty(_hip.load().vg_split_planes_bytes(n, _precision), dtype=torch.uint8, device=t.device)
+        call("vg_split_planes_f32", _ptr(t), ctypes.c_longlong(n), _precision, ctypes.c_void_p(planes.data_ptr()),
+             _stream())
         self.entries[key] = (t, t._version, planes)
         return ctypes.c_void_p(planes.data_ptr())
 

@@ -87,14 +87,16 @@ int vg_conv2d_wgrad_reduce(const vg_conv_geom* g, float* gw, const void* workspa
  * Shapes the bf16 tiles do not cover (operands that are not 16-byte vectors, e.g. a 3-channel image stem, and the
  * bandwidth-bound thin kernels) run in f32 under every setting.
  * Workspace: vg_conv2d_prec_workspace_bytes(mode, g, precision) bytes, 256-byte aligned (0 = none needed). The split
- * mode keeps the bf16 terms of both operands there (written by a splitting kernel ahead of the contraction); for
+ * and bf16 modes keep the bf16 terms of both operands there (written by a converting kernel ahead of the contraction,
+ * unless the caller hands them over; VG_BF16_PLANES=0 in the environment makes the bf16 mode convert inside the
+ * contraction's tile loader instead); for
  * mode 2 the size includes the split-K slabs of vg_conv2d_wgrad_workspace_bytes, which come first, so
  * vg_conv2d_wgrad_reduce takes the same pointer. */
 enum { VG_PREC_F32 = 0, VG_PREC_BF16 = 1, VG_PREC_F32_SPLIT = 2 };
 size_t vg_conv2d_prec_workspace_bytes(int mode, const vg_conv_geom* g, int precision);   /* mode 0 fwd, 1 dgrad, 2 wgrad */
 /* The `*_planes` arguments (nullable) hand over an operand that the caller has already split with vg_split_planes_f32,
- * e.g. an activation that feeds both a forward contraction and, later, a weight gradient; they are only read in the
- * split mode, for shapes vg_conv2d_split_applies reports as served by it. */
+ * e.g. an activation that feeds both a forward contraction and, later, a weight gradient; they are only read for
+ * (mode, geometry, precision) combinations vg_conv2d_split_applies reports. */
 int vg_conv2d_fwd_prec(const vg_conv_geom* g, const float* x, const float* w, const float* bias, float* y,
                        int precision, void* workspace, size_t workspace_bytes, const void* x_planes,
                        const void* w_planes, void* stream);
@@ -104,11 +106,12 @@ int vg_conv2d_dgrad_prec(const vg_conv_geom* g, const float* gy, const float* w,
 int vg_conv2d_wgrad_partial_prec(const vg_conv_geom* g, const float* gy, const float* x, float* gw, void* workspace,
                                  size_t workspace_bytes, int precision, const void* gy_planes, const void* x_planes,
                                  void* stream);
-/* The three bf16 terms of `elements` f32 values, written one plane after the other into `planes`
- * (vg_split_planes_bytes(elements) bytes, 16-byte aligned); and whether the split mode serves (mode, geometry). */
-size_t vg_split_planes_bytes(long long elements);
-int vg_split_planes_f32(const float* in, long long elements, void* planes, void* stream);
-int vg_conv2d_split_applies(int mode, const vg_conv_geom* g);
+/* The bf16 terms of `elements` f32 values under `precision` (three in the split mode, the rounded value alone in the
+ * bf16 mode), written one plane after the other into `planes` (vg_split_planes_bytes bytes, 16-byte aligned); and
+ * whether (mode, geometry) runs on such pre-converted operands under `precision`. */
+size_t vg_split_planes_bytes(long long elements, int precision);
+int vg_split_planes_f32(const float* in, long long elements, int precision, void* planes, void* stream);
+int vg_conv2d_split_applies(int mode, const vg_conv_geom* g, int precision);
 
 /* Name of the kernel template instance the call for (mode, geometry) dispatches to (mode 0 fwd, 1 dgrad, 2 wgrad;
  * 16-byte aligned tensors assumed), as a kernel trace prints it.  No counterpart in the reference: it exists so a
