@@ -31,12 +31,15 @@ static __device__ __attribute__((aligned(16))) unsigned int vg_zero_page_u[4] = 
 
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 
-template <int MODE, int BM, int BN, int WAVES_M, int NP, int NW>
+template <int MODE, int BM, int BN, int WAVES_M, int NP, int NW, int BK_ = 32>
 __global__ void __launch_bounds__(NW * 64) pgemm_kernel(const PgemmParams pp) {
   const IgemmParams& p = pp.g;
   constexpr int NT = NW * 64;
-  constexpr int BK = 32;
-  constexpr int LDB = 40;                          // bf16 per row of a [row][k] tile
+  constexpr int BK = BK_;                          // k extent of a staged tile: 32, or 64 where LDS allows (one plane)
+  constexpr int KV = BK / 8;                       // 16-byte vectors per row of a [row][k] tile
+  constexpr int NS = BK / 16;                      // 16-deep MFMA slices per k-step
+  constexpr int LDB = BK + 8;                      // bf16 per row of a [row][k] tile (80- or 144-byte rows: conflict-free)
+  static_assert(BK == 32 || BK == 64, "two or four slices per k-step");
   constexpr int LDMA = BM + 32, LDMB = BN + 32;    // bf16 per k row of a [k][row] tile
   constexpr int WAVES_N = NW / WAVES_M;
   constexpr int TM = BM / (WAVES_M * 32), TN = BN / (WAVES_N * 32);
@@ -105,14 +108,14 @@ __global__ void __launch_bounds__(NW * 64) pgemm_kernel(const PgemmParams pp) {
   const int nk = (kend - kbeg + BK - 1) / BK;
 
   // ---- loader geometry: a thread owns 16-byte units (8 bf16) of each plane ----
-  // [row][k] tile: unit = (row, k8 = 8 * (tid & 3)), rows (tid >> 2) + (NT / 4) * i
+  // [row][k] tile: unit = (row, k8 = 8 * (tid % KV)), rows (tid / KV) + (NT / KV) * i
   // [k][row] tile: unit = (k, 8 rows), TPK threads per k row, k rows tid / TPK + (NT / TPK) * i
-  constexpr int UA_RK = (BM * 4 + NT - 1) / NT, UB_RK = (BN * 4 + NT - 1) / NT;
+  constexpr int UA_RK = (BM * KV + NT - 1) / NT, UB_RK = (BN * KV + NT - 1) / NT;
   constexpr int TPKA = BM / 8, TPKB = BN / 8;
   constexpr int UA_MC = (BK * TPKA + NT - 1) / NT, UB_MC = (BK * TPKB + NT - 1) / NT;
   constexpr int UA = A_MC ? UA_MC : UA_RK, UB = B_MC ? UB_MC : UB_RK;
-  auto rowA = [&](int i) -> int { return (tid >> 2) + (NT / 4) * i; };    // [row][k] tiles
-  auto rowB = [&](int i) -> int { return (tid >> 2) + (NT / 4) * i; };
+  auto rowA = [&](int i) -> int { return (tid / KV) + (NT / KV) * i; };    // [row][k] tiles
+  auto rowB = [&](int i) -> int { return (tid / KV) + (NT / KV) * i; };
   auto krowA = [&](int i) -> int { return tid / TPKA + (NT / TPKA) * i; };  // [k][row] tiles
   auto krowB = [&](int i) -> int { return tid / TPKB + (NT / TPKB) * i; };
 
@@ -164,7 +167,7 @@ __global__ void __launch_bounds__(NW * 64) pgemm_kernel(const PgemmParams pp) {
   const int a_steps = BK / a_cch, a_rem = BK - a_steps * a_cch;
   const float inv_ntw = ntw > 0 ? 1.0f / (float)ntw : 0.f;
   if constexpr (!A_MC) {
-    const int k8 = kbeg + 8 * (tid & 3);
+    const int k8 = kbeg + 8 * (tid % KV);
     ak_t = k8 / a_cch;
     ak_c = k8 - ak_t * a_cch;
   }
@@ -205,7 +208,7 @@ __global__ void __launch_bounds__(NW * 64) pgemm_kernel(const PgemmParams pp) {
     const int kb = kpos;
     // ---------------- A ----------------
     if constexpr (!A_MC) {
-      const bool kvalid = kb + 8 * (tid & 3) < kend;
+      const bool kvalid = kb + 8 * (tid % KV) < kend;
       const int ak_ta = vg_div_small(ak_t, inv_ntw), ak_tb = ak_t - ak_ta * ntw;
 #pragma unroll
       for (int i = 0; i < UA; ++i) {
@@ -231,7 +234,7 @@ __global__ void __launch_bounds__(NW * 64) pgemm_kernel(const PgemmParams pp) {
     // ---------------- B ----------------
     if constexpr (!B_MC) {
       // fwd weights w[co][k]: tile [n][k]
-      const int k8 = kb + 8 * (tid & 3);
+      const int k8 = kb + 8 * (tid % KV);
 #pragma unroll
       for (int i = 0; i < UB; ++i) {
         const int n = n0 + rowB(i);
@@ -292,10 +295,10 @@ __global__ void __launch_bounds__(NW * 64) pgemm_kernel(const PgemmParams pp) {
 #pragma unroll
     for (int i = 0; i < UA; ++i) {
       if constexpr (!A_MC) {
-        if (BM * 4 % NT == 0 || rowA(i) < BM) {
+        if (BM * KV % NT == 0 || rowA(i) < BM) {
 #pragma unroll
           for (int q = 0; q < NP; ++q)
-            *reinterpret_cast<u32x4*>(&As[q * A_EL + rowA(i) * LDB + 8 * (tid & 3)]) = ra[buf][i][q];
+            *reinterpret_cast<u32x4*>(&As[q * A_EL + rowA(i) * LDB + 8 * (tid % KV)]) = ra[buf][i][q];
         }
       } else {
         if (BK * TPKA % NT == 0 || krowA(i) < BK) {
@@ -308,10 +311,10 @@ __global__ void __launch_bounds__(NW * 64) pgemm_kernel(const PgemmParams pp) {
 #pragma unroll
     for (int i = 0; i < UB; ++i) {
       if constexpr (!B_MC) {
-        if (BN * 4 % NT == 0 || rowB(i) < BN) {
+        if (BN * KV % NT == 0 || rowB(i) < BN) {
 #pragma unroll
           for (int q = 0; q < NP; ++q)
-            *reinterpret_cast<u32x4*>(&Bs[q * B_EL + rowB(i) * LDB + 8 * (tid & 3)]) = rb[buf][i][q];
+            *reinterpret_cast<u32x4*>(&Bs[q * B_EL + rowB(i) * LDB + 8 * (tid % KV)]) = rb[buf][i][q];
         }
       } else {
         if (BK * TPKB % NT == 0 || krowB(i) < BK) {
@@ -383,7 +386,7 @@ __global__ void __launch_bounds__(NW * 64) pgemm_kernel(const PgemmParams pp) {
 
   bf16x8 afx[NP * TM], bfx[NP * TN], afy[NP * TM], bfy[NP * TN];
 
-  // One k-step on buffer `buf` (two 16-deep slices). On entry afx/bfx hold slice 0 and the other register stage holds
+  // One k-step on buffer `buf` (NS 16-deep slices). On entry afx/bfx hold slice 0 and the other register stage holds
   // tile kt+1 (loads issued two k-steps ago); it is written to the other buffer under the MFMAs, the loads of tile
   // kt+3 are issued into the freed stage, and after the barrier slice 0 of the next buffer is fetched under the MFMAs
   // of slice 1.
@@ -391,15 +394,22 @@ __global__ void __launch_bounds__(NW * 64) pgemm_kernel(const PgemmParams pp) {
   // conditional loads in the loop body the compiler can no longer count which loads are outstanding at the LDS store
   // and waits for all of them, the stage loaded one k-step ago included).
   auto k_step = [&](int kt, int buf, bool more) {
-    load_frags(buf, 1, afy, bfy);
-    __builtin_amdgcn_sched_barrier(0);
-    mma_frags(afx, bfx);
-    if (more || kt + 1 < nk) store_tiles(buf ^ 1);
-    if (more || kt + 3 < nk) load_tiles(buf ^ 1);
+#pragma unroll
+    for (int sl = 0; sl + 1 < NS; ++sl) {      // slices 0 .. NS-2: even ones sit in afx/bfx, odd ones in afy/bfy
+      if (sl & 1) load_frags(buf, sl + 1, afx, bfx);
+      else load_frags(buf, sl + 1, afy, bfy);
+      __builtin_amdgcn_sched_barrier(0);
+      if (sl & 1) mma_frags(afy, bfy);
+      else mma_frags(afx, bfx);
+      if (sl == 0) {
+        if (more || kt + 1 < nk) store_tiles(buf ^ 1);
+        if (more || kt + 3 < nk) load_tiles(buf ^ 1);
+      }
+    }
     __syncthreads();
     if (more || kt + 1 < nk) load_frags(buf ^ 1, 0, afx, bfx);
     __builtin_amdgcn_sched_barrier(0);
-    mma_frags(afy, bfy);
+    mma_frags(afy, bfy);                       // the last slice (odd)
   };
 
   if (nk > 0) {
@@ -457,10 +467,11 @@ __global__ void __launch_bounds__(NW * 64) pgemm_kernel(const PgemmParams pp) {
 // Tiles served: 128x128, 128x64, 64x128 (eight waves) and 64x64 (four waves).
 template <int MODE, int NP>
 static inline int pgemm_launch(const PgemmParams& pp, int bm, int bn, dim3 grid, hipStream_t st) {
-  if (bm == 128 && bn == 128) hipLaunchKernelGGL((pgemm_kernel<MODE, 128, 128, 2, NP, 8>), grid, dim3(512), 0, st, pp);
-  else if (bm == 128 && bn == 64) hipLaunchKernelGGL((pgemm_kernel<MODE, 128, 64, 4, NP, 8>), grid, dim3(512), 0, st, pp);
-  else if (bm == 64 && bn == 128) hipLaunchKernelGGL((pgemm_kernel<MODE, 64, 128, 2, NP, 8>), grid, dim3(512), 0, st, pp);
-  else if (bm == 64 && bn == 64) hipLaunchKernelGGL((pgemm_kernel<MODE, 64, 64, 2, NP, 4>), grid, dim3(256), 0, st, pp);
+  constexpr int BK = NP == 1 ? 64 : 32;     // a single plane leaves room for 64-deep tiles: half the barriers per flop
+  if (bm == 128 && bn == 128) hipLaunchKernelGGL((pgemm_kernel<MODE, 128, 128, 2, NP, 8, BK>), grid, dim3(512), 0, st, pp);
+  else if (bm == 128 && bn == 64) hipLaunchKernelGGL((pgemm_kernel<MODE, 128, 64, 4, NP, 8, BK>), grid, dim3(512), 0, st, pp);
+  else if (bm == 64 && bn == 128) hipLaunchKernelGGL((pgemm_kernel<MODE, 64, 128, 2, NP, 8, BK>), grid, dim3(512), 0, st, pp);
+  else if (bm == 64 && bn == 64) hipLaunchKernelGGL((pgemm_kernel<MODE, 64, 64, 2, NP, 4, BK>), grid, dim3(256), 0, st, pp);
   else return -1;
   return 0;
 }
