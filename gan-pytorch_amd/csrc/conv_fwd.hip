@@ -19,6 +19,7 @@ int vg_check_geom(const vg_conv_geom* g, const char* who) {
 
 int vg_try_fwd_thin(const vg_conv_geom* g, const float* x, const float* w, const float* bias, float* y, hipStream_t st);
 int vg_thin_dgrad_applies(const vg_conv_geom* g);
+int vg_stem_fwd_applies(const vg_conv_geom* g);
 
 static int check_precision(int precision, const char* who) {
   if (precision < VG_PREC_F32 || precision > VG_PREC_F32_SPLIT) return vg_fail(VG_ERR_INVALID, "%s: unknown precision %d", who, precision);
@@ -108,6 +109,10 @@ extern "C" int vg_conv2d_variant(int mode, const vg_conv_geom* g, char* buf, siz
   long long rows = (long long)g->N * g->Ho * g->Wo;
   if (mode == 0 && g->Co <= 4 && g->Ci % 4 == 0) {
     snprintf(buf, len, "fwd_thin_kernel<%d, %d>", g->Co, g->kh * g->kw * g->Ci >= 2048 ? 256 : 64);
+    return VG_OK;
+  }
+  if (mode == 0 && vg_stem_fwd_applies(g)) {
+    snprintf(buf, len, "stem_fwd_kernel<%d, %d, %d>", g->Ci, g->kh, g->sh);
     return VG_OK;
   }
   const bool gemm_dgrad = g->Ho == 1 && g->Wo == 1 && g->ph == 0 && g->pw == 0 && g->H == g->kh && g->W == g->kw;

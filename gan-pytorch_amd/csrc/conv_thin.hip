@@ -278,7 +278,160 @@ __global__ void __launch_bounds__(256) dgrad_scatter_kernel(const float* __restr
 }  // namespace
 
 // Returns 1 if the thin forward kernel took the call, 0 if the shape does not qualify, < 0 on error.
+// the (channels, taps, stride) combinations stem_fwd_kernel is instantiated for
+int vg_stem_fwd_applies(const vg_conv_geom* g) {
+  if (g->Ci > 4 || g->Co % 32 != 0 || g->kh != g->kw || g->sh != g->sw) return 0;
+  const bool c = g->Ci == 3 || g->Ci == 1;
+  return c && ((g->kh == 4 && g->sh == 2) || (g->kh == 3 && g->sh == 1) || (g->kh == 5 && g->sh == 2));
+}
+
+namespace {
+
+// Forward convolution of an image stem: at most 4 input channels (K = KK*KK*CI is a few dozen), output channels in
+// multiples of 32. The generic implicit GEMM gathers such an operand with one bounds-checked 4-byte load per element;
+// here a block stages the input patch of its output pixels in LDS with coalesced row loads (zero filled where the
+// window leaves the image), and every lane reads its A values of v_mfma_f32_32x32x2_f32 from the patch at compile-time
+// offsets, while the weight fragments of the block's 64 output channels stay in registers. A block is 4 waves; wave v
+// owns output row ho0 + v of the tile, 32 consecutive output columns; blockIdx.y walks the channel tiles.
+template <int CI, int KK, int S>
+__global__ void __launch_bounds__(256) stem_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                       const float* __restrict__ bias, float* __restrict__ y, int H, int W,
+                                                       int Co, int Ho, int Wo, int ph, int pw, int tiles_w, int tiles_h,
+                                                       int tiles_total) {
+  constexpr int K = KK * KK * CI, KP = (K + 1) / 2;
+  constexpr int TW = 32, TH = 4;
+  constexpr int PWID = (TW - 1) * S + KK, PH = (TH - 1) * S + KK;   // patch extent in input pixels
+  constexpr int ROWF = PWID * CI;                                   // floats per patch row
+  constexpr int LDW = K | 1;                                        // odd weight row stride: conflict-free column reads
+  __shared__ float patch[PH * ROWF];
+  __shared__ float wsm[64 * LDW];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int co0 = blockIdx.y * 64;
+  const bool two = co0 + 32 < Co;     // the second 32-channel tile exists
+
+  // the block's 64 weight rows come in coalesced through LDS; lane (col = r, half = h) keeps w[co0 + 32 t + r][2 j + h]
+  // in registers for all the tiles the block walks
+  for (int i = threadIdx.x; i < 64 * K; i += 256) {
+    const int row = i / K, k = i - row * K;
+    wsm[row * LDW + k] = co0 + row < Co ? w[(size_t)(co0 + row) * K + k] : 0.f;
+  }
+  __syncthreads();
+  float bw[2][KP];
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int j = 0; j < KP; ++j) {
+      const int k = 2 * j + h;
+      bw[t][j] = k < K ? wsm[(32 * t + r) * LDW + k] : 0.f;
+    }
+  float bv[2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t) bv[t] = (bias && co0 + 32 * t + r < Co) ? bias[co0 + 32 * t + r] : 0.f;
+
+  // patch element i of a thread: row pr, pixel px, channel pc (the same for every tile)
+  constexpr int PPT = (PH * ROWF + 255) / 256;
+  int p_row[PPT], p_px[PPT], p_c[PPT];
+#pragma unroll
+  for (int u = 0; u < PPT; ++u) {
+    const int i = threadIdx.x + 256 * u;
+    p_row[u] = i / ROWF;
+    const int pc = i - p_row[u] * ROWF;
+    p_px[u] = pc / CI;
+    p_c[u] = pc - p_px[u] * CI;
+    if (i >= PH * ROWF) p_row[u] = -(1 << 28);
+  }
+  float pre[PPT];
+  auto fetch_patch = [&](int tile) {       // zero where the window leaves the image
+    int bid = tile;
+    const int tw = bid % tiles_w; bid /= tiles_w;
+    const int th = bid % tiles_h;
+    const int n = bid / tiles_h;
+    const int hi0 = th * TH * S - ph, wi0 = tw * TW * S - pw;
+    const float* img = x + (size_t)n * H * W * CI;
+#pragma unroll
+    for (int u = 0; u < PPT; ++u) {
+      const int hi = hi0 + p_row[u], wi = wi0 + p_px[u];
+      pre[u] = ((unsigned)hi < (unsigned)H && (unsigned)wi < (unsigned)W) ? img[((size_t)hi * W + wi) * CI + p_c[u]] : 0.f;
+    }
+  };
+  if ((int)blockIdx.x < tiles_total) fetch_patch(blockIdx.x);
+
+  for (int tile = blockIdx.x; tile < tiles_total; tile += gridDim.x) {
+    int bid = tile;
+    const int tw = bid % tiles_w; bid /= tiles_w;
+    const int th = bid % tiles_h;
+    const int n = bid / tiles_h;
+    const int ho0 = th * TH, wo0 = tw * TW;
+    __syncthreads();      // the previous tile's reads are done
+#pragma unroll
+    for (int u = 0; u < PPT; ++u) {
+      const int i = threadIdx.x + 256 * u;
+      if (i < PH * ROWF) patch[i] = pre[u];
+    }
+    __syncthreads();
+    if (tile + (int)gridDim.x < tiles_total) fetch_patch(tile + gridDim.x);   // in flight under the MFMAs below
+
+    f32x16 acc[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
+    // A[pixel r of this wave's row][k] = patch[(wave*S + kh) * ROWF + (r*S + kw) * CI + ci], k = (kh*KK + kw)*CI + ci
+    const float* base = patch + wave * S * ROWF + r * S * CI;
+#pragma unroll
+    for (int j = 0; j < KP; ++j) {
+      constexpr int KC = KK * CI;
+      const int k0 = 2 * j, k1 = 2 * j + 1;
+      const int o0 = (k0 / KC) * ROWF + (k0 % KC);
+      const int o1 = k1 < K ? (k1 / KC) * ROWF + (k1 % KC) : o0;
+      float a = base[h ? o1 : o0];
+      if (k1 >= K && h) a = 0.f;
+      acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bw[0][j], acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bw[1][j], acc[1], 0, 0, 0);
+    }
+    const int ho = ho0 + wave;
+    if (ho < Ho) {
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        if (t == 1 && !two) break;
+        const int co = co0 + 32 * t + r;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int wo = wo0 + (e & 3) + 8 * (e >> 2) + 4 * h;
+          if (wo < Wo) y[((size_t)(n * Ho + ho) * Wo + wo) * Co + co] = acc[t][e] + bv[t];
+        }
+      }
+    }
+  }
+}
+
+int try_fwd_stem(const vg_conv_geom* g, const float* x, const float* w, const float* bias, float* y, hipStream_t st) {
+  if (!vg_stem_fwd_applies(g)) return 0;
+  const int tiles_w = (g->Wo + 31) / 32, tiles_h = (g->Ho + 3) / 4;
+  const long long blocks = (long long)tiles_w * tiles_h * g->N;
+  if (blocks > 0x7fffffffLL) return 0;
+  // a block keeps its weight fragments in registers and walks tiles: about four blocks per CU
+  dim3 grid((unsigned)(blocks < 1024 ? blocks : 1024), (unsigned)((g->Co + 63) / 64));
+  bool done = false;
+#define STEM_FWD(CI_, KK_, S_)                                                                                          \
+  if (!done && g->Ci == CI_ && g->kh == KK_ && g->sh == S_) {                                                          \
+    hipLaunchKernelGGL((stem_fwd_kernel<CI_, KK_, S_>), grid, dim3(256), 0, st, x, w, bias, y, g->H, g->W, g->Co, g->Ho, \
+                       g->Wo, g->ph, g->pw, tiles_w, tiles_h, (int)blocks);                                           \
+    done = true;                                                                                                       \
+  }
+  STEM_FWD(3, 4, 2) STEM_FWD(1, 4, 2) STEM_FWD(3, 3, 1) STEM_FWD(1, 3, 1) STEM_FWD(3, 5, 2) STEM_FWD(1, 5, 2)
+#undef STEM_FWD
+  if (!done) return 0;
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return vg_fail(VG_ERR_LAUNCH, "vg_conv2d_fwd(stem): launch failed: %s", hipGetErrorString(e));
+  return 1;
+}
+
+}  // namespace
+
 int vg_try_fwd_thin(const vg_conv_geom* g, const float* x, const float* w, const float* bias, float* y, hipStream_t st) {
+  if (int r = try_fwd_stem(g, x, w, bias, y, st)) return r;
   const int K = g->kh * g->kw * g->Ci;
   if (g->Co > 4 || g->Ci % 4 != 0 || !vg_aligned16(x) || !vg_aligned16(w)) return 0;
   const int M = g->N * g->Ho * g->Wo;

@@ -35,6 +35,10 @@ CONV_CASES = [
     (2, 4, 37, 21, 8, 4, 2, 1),      # Ci=4, several row tiles, odd sizes
     (8, 3, 64, 64, 16, 4, 2, 1),     # image stem at full resolution: per-pixel stem kernel forward
     (4, 1, 40, 40, 8, 3, 1, 1),      # stem kernel, 3x3 stride 1, Ci=1
+    (8, 3, 64, 64, 64, 4, 2, 1),     # DCGAN image stem: MFMA stem kernel, one block tile per 4 x 32 output pixels
+    (3, 1, 12, 12, 32, 5, 2, 2),     # stem kernel, Ci=1, 5x5 stride 2, ragged tile (6 x 6 outputs), one channel tile
+    (2, 3, 9, 7, 96, 3, 1, 1),       # stem kernel, 3x3 stride 1 (odd K = 27), 96 channels: second grid row half filled
+    (5, 1, 21, 70, 64, 4, 2, 1),     # stem kernel, Ci=1, several column tiles with a ragged last one
 ]
 
 
