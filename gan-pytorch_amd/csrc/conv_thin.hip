@@ -193,6 +193,19 @@ __global__ void __launch_bounds__(256) dgrad_scatter_kernel(const float* __restr
       src[j] = ((unsigned)qh < (unsigned)Ho && (unsigned)qw < (unsigned)Wo)
                    ? ((long long)(n * Ho + qh) * Wo + qw) * Co + 4 * (threadIdx.x & 7) : -1;
     }
+    // partial[pixel][k] = sum over co of gy[pixel][co] * w[co][k] on the matrix cores: wave v owns pixels
+    // 64 v .. 64 v + 63 (two 32-row tiles) and all ceil(NP / 32) column tiles; per 32-channel chunk its A values come
+    // from the staged tile and its B values (lane = column, coalesced rows of w) straight from memory.
+    constexpr int NTN = (NP + 31) / 32;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 31, hh = lane >> 5;
+    f32x16 macc[2][NTN];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NTN; ++nt)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) macc[mt][nt][e] = 0.f;
     for (int cc0 = 0; cc0 < Co; cc0 += CCH) {
       __syncthreads();
 #pragma unroll
@@ -201,21 +214,41 @@ __global__ void __launch_bounds__(256) dgrad_scatter_kernel(const float* __restr
         if (src[j] >= 0 && cc0 + 4 * (int)(threadIdx.x & 7) < Co) v = *reinterpret_cast<const f32x4*>(gy + src[j] + cc0);
         *reinterpret_cast<f32x4*>(&stage[((threadIdx.x >> 3) + 32 * j) * LDS_ + 4 * (threadIdx.x & 7)]) = v;
       }
+      float bfr[CCH / 2][NTN];
+#pragma unroll
+      for (int j = 0; j < CCH / 2; ++j) {
+        const int co = cc0 + 2 * j + hh;
+#pragma unroll
+        for (int nt = 0; nt < NTN; ++nt) {
+          const int col = 32 * nt + r;
+          bfr[j][nt] = (co < Co && col < NP) ? w[(size_t)co * NP + col] : 0.f;
+        }
+      }
       __syncthreads();
-      if (mine) {
-        const int cmax = min(CCH, Co - cc0);
-        for (int c4 = 0; c4 < cmax; c4 += 4) {
-          const f32x4 gv = *reinterpret_cast<const f32x4*>(&stage[threadIdx.x * LDS_ + c4]);
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const float* wc = w + (size_t)(cc0 + c4 + e) * NP;
+      for (int j = 0; j < CCH / 2; ++j) {
+        const float a0 = stage[(64 * wave + r) * LDS_ + 2 * j + hh];
+        const float a1 = stage[(64 * wave + 32 + r) * LDS_ + 2 * j + hh];
 #pragma unroll
-            for (int k = 0; k < NP; ++k) acc[k] = fmaf(gv[e], wc[k], acc[k]);
-          }
+        for (int nt = 0; nt < NTN; ++nt) {
+          macc[0][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bfr[j][nt], macc[0][nt], 0, 0, 0);
+          macc[1][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, bfr[j][nt], macc[1][nt], 0, 0, 0);
         }
       }
     }
     __syncthreads();
+    // accumulator element e of a lane is row (e & 3) + 8 (e >> 2) + 4 hh, column r of its 32 x 32 tile
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NTN; ++nt) {
+        const int col = 32 * nt + r;
+        if (col < NP) {
+#pragma unroll
+          for (int e = 0; e < 16; ++e)
+            part[(64 * wave + 32 * mt + (e & 3) + 8 * (e >> 2) + 4 * hh) * LDP + col] = macc[mt][nt][e];
+        }
+      }
   } else if (mine) {
     const float* g = gy + ((size_t)(n * Ho + ho) * Wo + wo) * Co;
     // the next quad of channels is fetched while the current one is being used
@@ -232,8 +265,10 @@ __global__ void __launch_bounds__(256) dgrad_scatter_kernel(const float* __restr
       gv = gn;
     }
   }
+  if constexpr (!kStaged) {
 #pragma unroll
-  for (int k = 0; k < NP; ++k) part[threadIdx.x * LDP + k] = acc[k];
+    for (int k = 0; k < NP; ++k) part[threadIdx.x * LDP + k] = acc[k];
+  }
   __syncthreads();
 
   // output pixels owned by this tile: rows whose lowest contributing gy row lies in [h0, h0 + step_h) (all rows when
