@@ -10,10 +10,11 @@
 // kh*kw/(sh*sw) * (number of column tiles) times: converted in the tile loader, the conversions cost more issue
 // slots than the MFMAs they feed.
 //
-// The three contractions and their row/column/k meanings are those of igemm.h.  Tiles are BM x BN x 32, staged
+// The three contractions and their row/column/k meanings are those of igemm.h.  Tiles are BM x BN x BK (BK = 32 with
+// three planes, 64 with one), staged
 // global -> registers -> LDS in 16-byte vectors of 8 bf16 (so every channel count involved must be a multiple
 // of 8), double buffered, one barrier per k-step.  A tile whose global image is contiguous along k is kept
-// [row][k] with 80-byte rows (conflict-free ds_read_b128 of a lane's 8 k values); one that is contiguous along
+// [row][k] with 2 * BK + 16 byte rows (conflict-free ds_read_b128 of a lane's 8 k values); one that is contiguous along
 // the row index is kept [k][row] as loaded and read back with ds_read_b64_tr_b16, which hands lane i of a 16-lane
 // group column i of a 4 x 16 block, i.e. 4 consecutive k of one row - the MFMA operand order - without any register
 // shuffling.  Its row stride is (rows / 2 + 16) dwords, which puts the four k rows of a block 16 banks apart.
