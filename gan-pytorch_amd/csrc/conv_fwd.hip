@@ -75,6 +75,24 @@ extern "C" int vg_conv2d_fwd_prec(const vg_conv_geom* g, const float* x, const f
   return VG_OK;
 }
 
+int vg_try_fwd_stem_act(const vg_conv_geom* g, const float* x, const float* w, const float* bias, float* y, int act,
+                        float slope, hipStream_t st);
+
+extern "C" int vg_conv2d_fwd_act_applies(const vg_conv_geom* g, int act) {
+  if (vg_check_geom(g, "vg_conv2d_fwd_act_applies")) return 0;
+  return (act == VG_ACT_RELU || act == VG_ACT_LRELU) && vg_stem_fwd_applies(g) ? 1 : 0;
+}
+
+extern "C" int vg_conv2d_fwd_act(const vg_conv_geom* g, const float* x, const float* w, const float* bias, float* y,
+                                 int act, float slope, void* stream) {
+  if (int e = vg_check_geom(g, "vg_conv2d_fwd_act")) return e;
+  VG_REQUIRE(x && w && y, "vg_conv2d_fwd_act: null tensor pointer");
+  if (!vg_conv2d_fwd_act_applies(g, act))
+    return vg_fail(VG_ERR_INVALID, "vg_conv2d_fwd_act: no fused kernel for this geometry / activation");
+  const int r = vg_try_fwd_stem_act(g, x, w, bias, y, act, slope, (hipStream_t)stream);
+  return r < 0 ? r : VG_OK;
+}
+
 // Plain GEMM out[M][Ncols] = A[M][K] * B[K][Ncols] (+ bias[col % bias_mod]); used by vg_conv2d_dgrad when the
 // gradient image is 1x1 (ConvTranspose2d applied to a latent vector): every tap then hits exactly one output
 // pixel and the transposed convolution is a single GEMM against the weight viewed as [Co][kh*kw*Ci].

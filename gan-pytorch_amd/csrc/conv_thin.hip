@@ -332,7 +332,7 @@ template <int CI, int KK, int S>
 __global__ void __launch_bounds__(256) stem_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                        const float* __restrict__ bias, float* __restrict__ y, int H, int W,
                                                        int Co, int Ho, int Wo, int ph, int pw, int tiles_w, int tiles_h,
-                                                       int tiles_total) {
+                                                       int tiles_total, int act, float slope) {
   constexpr int K = KK * KK * CI, KP = (K + 1) / 2;
   constexpr int TW = 32, TH = 4;
   constexpr int PWID = (TW - 1) * S + KK, PH = (TH - 1) * S + KK;   // patch extent in input pixels
@@ -434,14 +434,18 @@ __global__ void __launch_bounds__(256) stem_fwd_kernel(const float* __restrict__
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
           const int wo = wo0 + (e & 3) + 8 * (e >> 2) + 4 * h;
-          if (wo < Wo) y[((size_t)(n * Ho + ho) * Wo + wo) * Co + co] = acc[t][e] + bv[t];
+          float v = acc[t][e] + bv[t];
+          if (act == VG_ACT_RELU) v = v > 0.f ? v : 0.f;
+          else if (act == VG_ACT_LRELU) v = v > 0.f ? v : v * slope;
+          if (wo < Wo) y[((size_t)(n * Ho + ho) * Wo + wo) * Co + co] = v;
         }
       }
     }
   }
 }
 
-int try_fwd_stem(const vg_conv_geom* g, const float* x, const float* w, const float* bias, float* y, hipStream_t st) {
+int try_fwd_stem(const vg_conv_geom* g, const float* x, const float* w, const float* bias, float* y, hipStream_t st,
+                 int act, float slope) {
   if (!vg_stem_fwd_applies(g)) return 0;
   const int tiles_w = (g->Wo + 31) / 32, tiles_h = (g->Ho + 3) / 4;
   const long long blocks = (long long)tiles_w * tiles_h * g->N;
@@ -452,7 +456,7 @@ int try_fwd_stem(const vg_conv_geom* g, const float* x, const float* w, const fl
 #define STEM_FWD(CI_, KK_, S_)                                                                                          \
   if (!done && g->Ci == CI_ && g->kh == KK_ && g->sh == S_) {                                                          \
     hipLaunchKernelGGL((stem_fwd_kernel<CI_, KK_, S_>), grid, dim3(256), 0, st, x, w, bias, y, g->H, g->W, g->Co, g->Ho, \
-                       g->Wo, g->ph, g->pw, tiles_w, tiles_h, (int)blocks);                                           \
+                       g->Wo, g->ph, g->pw, tiles_w, tiles_h, (int)blocks, act, slope);                               \
     done = true;                                                                                                       \
   }
   STEM_FWD(3, 4, 2) STEM_FWD(1, 4, 2) STEM_FWD(3, 3, 1) STEM_FWD(1, 3, 1) STEM_FWD(3, 5, 2) STEM_FWD(1, 5, 2)
@@ -465,8 +469,14 @@ int try_fwd_stem(const vg_conv_geom* g, const float* x, const float* w, const fl
 
 }  // namespace
 
+// Stem forward with ReLU / LeakyReLU applied to the result before it is stored; 0 when the stem kernel does not apply.
+int vg_try_fwd_stem_act(const vg_conv_geom* g, const float* x, const float* w, const float* bias, float* y, int act,
+                        float slope, hipStream_t st) {
+  return try_fwd_stem(g, x, w, bias, y, st, act, slope);
+}
+
 int vg_try_fwd_thin(const vg_conv_geom* g, const float* x, const float* w, const float* bias, float* y, hipStream_t st) {
-  if (int r = try_fwd_stem(g, x, w, bias, y, st)) return r;
+  if (int r = try_fwd_stem(g, x, w, bias, y, st, VG_ACT_NONE, 0.f)) return r;
   const int K = g->kh * g->kw * g->Ci;
   if (g->Co > 4 || g->Ci % 4 != 0 || !vg_aligned16(x) || !vg_aligned16(w)) return 0;
   const int M = g->N * g->Ho * g->Wo;

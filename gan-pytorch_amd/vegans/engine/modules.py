@@ -18,8 +18,8 @@ def _pair(v):
 
 
 class HipConv2d(nn.Conv2d):
-    def forward(self, x):
-        return ops.conv2d(x, self.weight, self.bias, _pair(self.stride), _pair(self.padding))
+    def forward(self, x, act=_hip.ACT_NONE, slope=0.0):
+        return ops.conv2d(x, self.weight, self.bias, _pair(self.stride), _pair(self.padding), act, slope)
 
 
 class HipConvTranspose2d(nn.ConvTranspose2d):
@@ -109,8 +109,9 @@ def _has_hooks(m):
 
 
 def _fused_act(norm, act):
-    """(code, slope) when `act` directly behind `norm` can run inside the norm's kernels, else None."""
-    if not isinstance(norm, (HipBatchNorm2d, HipBatchNorm1d)) or _has_hooks(norm) or _has_hooks(act):
+    """(code, slope) when `act` directly behind `norm` (a BatchNorm, or a convolution: ops.conv2d decides per geometry
+    whether its epilogue takes the activation) can run inside that layer's kernels, else None."""
+    if not isinstance(norm, (HipBatchNorm2d, HipBatchNorm1d, HipConv2d)) or _has_hooks(norm) or _has_hooks(act):
         return None
     if type(act) is HipReLU:
         return _hip.ACT_RELU, 0.0
@@ -120,7 +121,8 @@ def _fused_act(norm, act):
 
 
 class HipSequential(nn.Sequential):
-    """nn.Sequential that runs a BatchNorm followed by ReLU / LeakyReLU as one fused operator: the normalised
+    """nn.Sequential that runs a BatchNorm (or, where the library has a fused kernel, a convolution) followed by
+    ReLU / LeakyReLU as one fused operator: the
     pre-activation tensor is never written, and the backward kernels apply the slope mask on the fly. The pairing
     is decided per call from the children actually present, so edits to the container keep working."""
 

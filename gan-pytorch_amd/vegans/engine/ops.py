@@ -372,6 +372,37 @@ class ConvFwdFn(Function):
         return gx, gw, gb, None
 
 
+class ConvActFn(Function):
+    """y = act(conv(x, w) + bias) with ReLU / LeakyReLU applied in the convolution's epilogue (the pre-activation is
+    never written). The slope mask of the backward pass is read off the sign of y, which for a non-negative slope is
+    the sign of the pre-activation; from there on the backward is that of the plain convolution."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias, g, act, slope):
+        xm, wm = to_nhwc(x), _weight_mem(w)
+        _check_shape(xm, g.x_shape(), "conv input")
+        if wm.numel() != g.w_numel():
+            raise _hip.HipError("weight has %d elements, geometry expects %d" % (wm.numel(), g.w_numel()))
+        y = _new_act(g.N, g.Co, g.Ho, g.Wo, xm, g.flat)
+        _launch_conv(0, g, lambda: call("vg_conv2d_fwd_act", ctypes.byref(g.c), _ptr(xm), _ptr(wm), _ptr(bias), _ptr(y),
+                                        act, c_float(slope), _stream()))
+        ctx.g, ctx.act, ctx.slope = g, act, slope
+        ctx.has_bias = bias is not None
+        ctx.save_for_backward(x, w, y)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w, y = ctx.saved_tensors
+        g = ctx.g
+        gpre = ActBwdFn.apply(gy, y, ctx.act, ctx.slope)
+        params = not inputs_only.active
+        gx = ConvDgradFn.apply(gpre, w, None, g) if ctx.needs_input_grad[0] else None
+        gw = ConvWgradFn.apply(gpre, x, g, tuple(w.shape)) if (params and ctx.needs_input_grad[1]) else None
+        gb = ColSumFn.apply(gpre) if (params and ctx.has_bias and ctx.needs_input_grad[2]) else None
+        return gx, gw, gb, None, None, None
+
+
 class ConvDgradFn(Function):
     """gx = conv_transpose(gy, w) (+bias over the Ci channels): also the forward of ConvTranspose2d."""
 
@@ -431,13 +462,19 @@ class ColSumFn(Function):
         return out
 
 
-def conv2d(x, w, bias, stride, padding):
+def conv2d(x, w, bias, stride, padding, act=_hip.ACT_NONE, slope=0.0):
+    """Convolution, optionally followed by ReLU / LeakyReLU (`act`, `slope`): fused into the convolution's epilogue
+    where the library has such a kernel for the geometry, otherwise applied as a separate operator."""
     n, ci, h, wd = x.shape
     co, ci_w, kh, kw = w.shape
     if ci_w != ci:
         raise _hip.HipError("Conv2d: input has %d channels, weight expects %d" % (ci, ci_w))
     g = Geom(n, h, wd, ci, co, kh, kw, stride[0], stride[1], padding[0], padding[1])
-    return ConvFwdFn.apply(x, w, bias, g)
+    if act == _hip.ACT_NONE:
+        return ConvFwdFn.apply(x, w, bias, g)
+    if slope >= 0.0 and _hip.load().vg_conv2d_fwd_act_applies(ctypes.byref(g.c), act):
+        return ConvActFn.apply(x, w, bias, g, act, float(slope))
+    return activation(ConvFwdFn.apply(x, w, bias, g), act, slope)
 
 
 def conv_transpose2d(x, w, bias, stride, padding, output_padding=(0, 0)):

@@ -72,6 +72,12 @@ int vg_conv2d_dgrad(const vg_conv_geom* g, const float* gy, const float* w, cons
 size_t vg_conv2d_wgrad_workspace_bytes(const vg_conv_geom* g);
 int vg_conv2d_wgrad(const vg_conv_geom* g, const float* gy, const float* x, float* gw,
                     void* workspace, size_t workspace_bytes, void* stream);
+/* y = act(conv(x, w) + bias) with act = VG_ACT_RELU / VG_ACT_LRELU applied as the result is stored, for the
+ * convolutions vg_conv2d_fwd_act_applies reports (today: image stems of at most 4 input channels, as the first layer
+ * of a critic without BatchNorm, `Conv2d -> LeakyReLU`); the pre-activation tensor is never written. */
+int vg_conv2d_fwd_act_applies(const vg_conv_geom* g, int act);
+int vg_conv2d_fwd_act(const vg_conv_geom* g, const float* x, const float* w, const float* bias, float* y, int act,
+                      float slope, void* stream);
 /* The two phases of vg_conv2d_wgrad as separate calls (contraction into split-K slabs, then the ordered slab sum), so
  * that a caller can time or overlap them individually; same arguments, same results. */
 int vg_conv2d_wgrad_partial(const vg_conv_geom* g, const float* gy, const float* x, float* gw,

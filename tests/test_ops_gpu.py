@@ -518,6 +518,60 @@ def test_gradient_penalty_with_bn_critic_double_backward(gpu, fused):
         _close(a.grad, b.grad, tol=1e-3, what="penalty grad " + name)
 
 
+@pytest.mark.parametrize("act,slope", [("lrelu", 0.2), ("relu", 0.0)])
+def test_stem_convolution_with_fused_activation(gpu, act, slope):
+    """Conv2d(3 -> 64) -> (Leaky)ReLU as the first layer of a BatchNorm-free critic stem: the activation runs in the
+    convolution's epilogue. Output, first-order gradients and the gradient-penalty (second-order) path against torch;
+    and the fused operator must equal the two separate operators bit for bit."""
+    from vegans import _hip
+    from vegans.engine import ops
+    g = torch.Generator().manual_seed(31)
+    B = 5
+    x = torch.randn(B, 3, 18, 14, generator=g)
+    w1 = torch.randn(64, 3, 4, 4, generator=g) * 0.2
+    b1 = torch.randn(64, generator=g) * 0.1
+    w2 = torch.randn(1, 64, 3, 3, generator=g) * 0.1
+    code = _hip.ACT_LRELU if act == "lrelu" else _hip.ACT_RELU
+    f_act = (lambda t: F.leaky_relu(t, slope)) if act == "lrelu" else F.relu
+
+    def run(critic, xs, ps, penalty, ones):
+        out = critic(xs, ps)
+        (gx,) = torch.autograd.grad(out, xs, ones(out), create_graph=True)
+        loss = penalty(gx) + out.mean()
+        loss.backward()
+        return out.detach(), gx.detach(), [p.grad for p in ps]
+
+    ref = lambda inp, p: F.conv2d(f_act(F.conv2d(inp, p[0], p[1], 2, 1)), p[2], None, 1, 0).flatten(1)
+    pr = [t.clone().requires_grad_(True) for t in (w1, b1, w2)]
+    out_r, gx_r, gr = run(ref, x.clone().requires_grad_(True), pr,
+                          lambda t: ((t.reshape(B, -1).norm(2, dim=1) - 1) ** 2).mean(), torch.ones_like)
+
+    def hip(fused):
+        def critic(inp, p):
+            if fused:
+                h = ops.conv2d(inp, p[0], p[1], (2, 2), (1, 1), code, slope)
+            else:
+                h = ops.activation(ops.conv2d(inp, p[0], p[1], (2, 2), (1, 1)), code, slope)
+            return ops.flatten(ops.conv2d(h, p[2], None, (1, 1), (0, 0)))
+        pd = [t.to(gpu).requires_grad_(True) for t in (w1, b1, w2)]
+        return run(critic, x.to(gpu).requires_grad_(True), pd, ops.gradient_penalty,
+                   lambda o: ops.fill_(torch.empty_like(o), 1.0))
+
+    lib = _hip.load()
+    import ctypes
+    geom = ops.Geom(B, 18, 14, 3, 64, 4, 4, 2, 2, 1, 1)
+    assert lib.vg_conv2d_fwd_act_applies(ctypes.byref(geom.c), code) == 1
+    out_f, gx_f, gf = hip(True)
+    out_s, gx_s, gs = hip(False)
+    _close(out_f, out_r, what="critic output")
+    _close(gx_f, gx_r, what="d critic / d input")
+    for name, a, b in zip(("w1", "b1", "w2"), gf, gr):
+        _close(a, b, tol=1e-3, what="gradient " + name)
+    assert torch.equal(out_f, out_s) and torch.equal(gx_f, gx_s)
+    for a, b in zip(gf, gs):
+        assert torch.equal(a, b)
+
+
 def test_gp_interpolate(gpu):
     from vegans.engine import ops
     g = torch.Generator().manual_seed(2)
