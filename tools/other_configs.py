@@ -33,6 +33,26 @@ def main():
     steps = int(sys.argv[1]) if len(sys.argv) > 1 else 10
     torch.manual_seed(0)
     np.random.seed(0)
+    # secondary variants of the headline configuration: BatchNorm-free critic (WGAN-GP paper practice), Adam
+    for label, bn, okw in (("BatchNorm-free critic, RMSprop", False, None),
+                           ("BatchNorm critic, Adam(1e-4, betas=(0.5, 0.9))", True,
+                            {"Generator": {"lr": 1e-4, "betas": (0.5, 0.9)}, "Adversariat": {"lr": 1e-4, "betas": (0.5, 0.9)}})):
+        with contextlib.redirect_stdout(io.StringIO()):
+            G = cfg.dcgan_init(cfg.dcgan_generator(100, 64, 3, 64), 1)
+            D = cfg.dcgan_init(cfg.dcgan_critic(64, 3, 64, batch_norm=bn), 2)
+            kw = dict(optim_kwargs=okw or {"Generator": {"lr": 1e-4}, "Adversariat": {"lr": 5e-5}})
+            if okw is not None:
+                kw["optim"] = {"Generator": torch.optim.Adam, "Adversariat": torch.optim.Adam}
+            m = gan.WassersteinGANGP(G, D, x_dim=(3, 64, 64), z_dim=(100, 1, 1), folder=None, fixed_noise_size=4, **kw)
+        m._create_steps(None)
+        m.train()
+        X = m._to_device(cfg.synthetic_images(256, (3, 64, 64), seed=1))
+        Z = torch.randn(256, 100, 1, 1, device="cuda")
+        dt = timed(m, (X, Z), steps)
+        print("WGAN-GP DCGAN-64, batch 256, %s, fp32: %.2f ms/iteration, %.0f images/s" % (label, 1e3 * dt, 256 / dt))
+        del m, X, Z
+        torch.cuda.empty_cache()
+
     with contextlib.redirect_stdout(io.StringIO()):
         G = cfg.dcgan_init(cfg.dcgan_generator(100, 64, 3, 128), 1)
         D = cfg.dcgan_init(cfg.dcgan_critic(64, 3, 128, batch_norm=True, sigmoid=True), 2)
