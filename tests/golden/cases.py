@@ -75,6 +75,9 @@ CASES = {
                            optim_kwargs={"Generator": {"lr": 5e-4}, "Adversariat": {"lr": 1e-4}}),
     "cvanilla_onehot": dict(cls="ConditionalVanillaGAN", algo="vanilla", nets="cond_conv", sigmoid=True,
                             x_dim=(1, 32, 32), z_dim=(1, 4, 4), y_dim=(10,), batch=8, n=16, data_range=(0.0, 1.0)),
+    "clsgan_onehot": dict(cls="ConditionalLSGAN", algo="lsgan", nets="cond_conv", sigmoid=True, x_dim=(1, 32, 32),
+                          z_dim=(1, 4, 4), y_dim=(10,), batch=8, n=24, data_range=(0.0, 1.0),
+                          optim_kwargs={"Generator": {"lr": 5e-4}, "Adversariat": {"lr": 2e-4}}),
     "pix2pix_small": dict(cls="ConditionalPix2Pix", algo="pix2pix", nets="img2img", x_dim=(3, 16, 16), z_dim=2,
                           y_dim=(3, 16, 16), batch=4, n=8, data_range=(0.0, 1.0)),
     "pix2pix_unet": dict(cls="ConditionalPix2Pix", algo="pix2pix", nets="unet", x_dim=(3, 32, 32), z_dim=2,

@@ -1,5 +1,5 @@
 """Where the host spends its time inside `fit()`, and whether it stays ahead of the GPU.
-    python tools/fit_host_timeline.py [batches]
+    python tools/fit_host_timeline.py [batches] [f64]
 Wraps the pieces of one iteration (upload of the next batch, latent draw, graph replay) with wall-clock timers and,
 right before every graph launch, asks whether the previous iteration has already finished on the device (then the GPU
 sat idle waiting for the host).
@@ -39,6 +39,9 @@ def main():
     np.random.seed(0)
     model = bench.build_model(None)
     X = cfg.synthetic_images(256 * batches, (3, 64, 64), seed=1)
+    if "f64" in sys.argv[2:]:
+        X = X.astype(np.float64)      # numpy's default dtype, what users of the reference typically pass
+    print("input dtype", X.dtype)
     kw = dict(batch_size=256, print_every=None, save_losses_every=None, enable_tensorboard=False)
     with contextlib.redirect_stdout(io.StringIO()):
         model.fit(X[:256 * 6], epochs=1, **kw)
