@@ -10,6 +10,7 @@ overlaps with the rest of backward; the rank's weight rows/global_rows is applie
 into its bucket, and the fused optimizer kernel then applies the identical update on every rank.  BatchNorm statistics stay per rank, as they
 are per replica under DataParallel.
 """
+import os
 from ctypes import c_float, c_size_t
 
 import torch
@@ -178,19 +179,29 @@ def _all_reduce_async(flat):
     return dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True)
 
 
+def _fenced():
+    """Whether the all-reduces between two graph launches are bracketed by device-wide host waits. Always with gloo,
+    whose device path runs copies on private streams from helper threads: next to HIP graph launches on one GPU that
+    deadlocked intermittently. RCCL collectives are ordinary stream-ordered work (the communication stream waits for
+    the launch stream through an event and the launch stream waits back), so nothing is fenced unless
+    VEGANS_DP_FENCE=1 asks for it: a fence drains the GPU three times per iteration and every graph then starts on an
+    idle device (measured with one RCCL rank at 256 rows: see tools/rccl_one_rank_rehearsal.py)."""
+    return _gloo() or os.environ.get("VEGANS_DP_FENCE", "0") == "1"
+
+
 def _all_reduce_now(flats):
-    """All-reduce gradient buckets between two graph launches of a replayed iteration. Blocking collectives (current
-    stream semantics), fenced by device-wide host waits on both sides, so that a graph launch never has a cross-stream
-    event wait pending in front of or behind it: the device is idle when the collective starts and idle again when the
-    next graph is launched. Two fenced collectives per network update cost a few hundred microseconds per iteration,
-    far less than enqueueing the iteration kernel by kernel."""
-    torch.cuda.synchronize()
+    """All-reduce gradient buckets between two graph launches of a replayed iteration, in stream order on the current
+    stream (blocking-collective semantics: the next graph launch is ordered behind them)."""
+    fenced = _fenced()
+    if fenced:
+        torch.cuda.synchronize()
     for f in flats:
         if _gloo() and f.is_cuda:
             _all_reduce_async(f)
         else:
             dist.all_reduce(f, op=dist.ReduceOp.SUM)
-    torch.cuda.synchronize()
+    if fenced:
+        torch.cuda.synchronize()
 
 
 def arm(model, who):

@@ -1,0 +1,101 @@
+"""Rehearsal of the data-parallel training loop on real RCCL with the one GPU a development box has.
+
+A one-rank `nccl` process group is created and the engine is told it is rank 0 of 2, so every piece of the multi-GPU
+path runs: row sharding, the gradient buckets and their hooks, the capture of an iteration into a chain of HIP graphs
+while RCCL's watchdog thread is alive, and RCCL all-reduces (over one rank: the identity) between the graph launches
+of every replay. Two runs from the same seeds, one replaying graphs and one eager, must end with the same parameters up to rounding.
+What it cannot show is the exchange between ranks itself.
+    python tools/rccl_one_rank_rehearsal.py [batches] [nccl|gloo]
+"""
+import contextlib
+import io
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "gan-pytorch_amd"))
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+import bench  # noqa: E402
+import bench_configs as cfg  # noqa: E402
+from vegans.engine import parallel  # noqa: E402
+
+ROWS = 512       # global batch: 256 rows per rank, the benchmark's per-GPU batch
+
+
+def run(batches, graphs, rows=ROWS):
+    os.environ["VEGANS_HIP_GRAPH_DP"] = "1" if graphs else "0"
+    if not dist.is_initialized():
+        os.environ["VEGANS_HIP_GRAPH"] = "1" if graphs else "0"
+    torch.manual_seed(0)
+    np.random.seed(0)
+    model = bench.build_model(ngpu=2 if dist.is_initialized() else None)
+    X = cfg.synthetic_images(rows * batches, (3, 64, 64), seed=1)
+    kw = dict(batch_size=rows, print_every=None, save_losses_every=None, enable_tensorboard=False)
+    with contextlib.redirect_stdout(io.StringIO()):
+        model.fit(X[:rows * 4], epochs=1, **kw)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        model.fit(X, epochs=1, **kw)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+    params = torch.cat([p.detach().flatten() for net in model.neural_nets.values() for p in net.parameters()])
+    return 1e3 * dt / batches, params.clone()
+
+
+def compare(what, a, b):
+    diff = (a - b).abs()
+    off = (diff > 1e-4).float().mean().item()
+    print("%s: largest parameter difference %.3g, share beyond 1e-4: %.2e" % (what, diff.max().item(), off), flush=True)
+    return diff.max().item(), off
+
+
+def main():
+    batches = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+    backend = sys.argv[2] if len(sys.argv) > 2 else "nccl"
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29531")
+    torch.cuda.set_device(0)
+    if backend == "none":       # control: the same four runs in one process without data parallelism
+        os.environ["VEGANS_HIP_GRAPH_DP"] = "1"
+    elif backend == "nccl":
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    else:
+        dist.init_process_group(backend, rank=0, world_size=1)
+    if dist.is_initialized():
+        print("backend", dist.get_backend(), "ranks", dist.get_world_size(), flush=True)
+        sharded = parallel._Sharded
+        parallel._dist_on = lambda: True
+        parallel._Sharded = lambda world, rank: sharded(2, 0)      # rank 0 of 2: trains on the first half of every batch
+    # A throw-away run first. The gradient penalty builds part of its autograd graph inside the engine's worker thread
+    # (create_graph=True), autograd orders ready nodes by per-thread sequence numbers, and the two threads' counters
+    # stand differently in the first run of a process than in later ones: the order in which the contributions to one
+    # weight gradient are added can differ in the last bit (stock PyTorch behaves the same), and RMSprop's first steps
+    # turn a last-bit difference in a noise-level gradient into a visible one.
+    run(2, False)
+    ms_graph, p_graph = run(batches, True)
+    print("graph chain + all-reduce between launches: %.2f ms per iteration (256 rows per rank)" % ms_graph, flush=True)
+    ms_eager, p_eager = run(batches, False)
+    print("eager + all-reduce from gradient hooks: %.2f ms per iteration" % ms_eager, flush=True)
+    _, p_graph2 = run(batches, True)
+    compare("graph vs graph again", p_graph, p_graph2)
+    if dist.is_initialized():
+        os.environ["VEGANS_DP_FENCE"] = "1"
+        ms_fenced, p_fenced = run(batches, True)
+        os.environ["VEGANS_DP_FENCE"] = "0"
+        print("graph chain with device-wide waits around the all-reduces: %.2f ms per iteration" % ms_fenced, flush=True)
+        compare("graph vs fenced graph", p_graph, p_fenced)
+    worst, off = compare("graph vs eager", p_graph, p_eager)
+    if dist.is_initialized():
+        dist.destroy_process_group()
+    if not torch.isfinite(p_graph).all() or worst > 2e-2 or off > 1e-3:
+        raise SystemExit("graph and eager data-parallel runs disagree")
+    print("ok")
+
+
+if __name__ == "__main__":
+    main()
