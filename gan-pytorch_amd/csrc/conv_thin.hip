@@ -162,7 +162,7 @@ __global__ void __launch_bounds__(256) dgrad_scatter_kernel(const float* __restr
                                                             int step_w, int org_h, int org_w) {
   constexpr int NP = TAPS * CI;
   constexpr int LDP = NP | 1;  // odd row stride: conflict-free column writes
-  __shared__ float part[256 * LDP];
+  __shared__ float part[256 * LDP + 256 * CI];   // partials, then one pass of finished output pixels
   const int RH = 256 / RW;
   int bid = blockIdx.x;
   const int tw = bid % tiles_w; bid /= tiles_w;
@@ -193,60 +193,69 @@ __global__ void __launch_bounds__(256) dgrad_scatter_kernel(const float* __restr
       src[j] = ((unsigned)qh < (unsigned)Ho && (unsigned)qw < (unsigned)Wo)
                    ? ((long long)(n * Ho + qh) * Wo + qw) * Co + 4 * (threadIdx.x & 7) : -1;
     }
-    // partial[pixel][k] = sum over co of gy[pixel][co] * w[co][k] on the matrix cores: wave v owns pixels
-    // 64 v .. 64 v + 63 (two 32-row tiles) and all ceil(NP / 32) column tiles; per 32-channel chunk its A values come
+    // partial[pixel][k] = sum over co of gy[pixel][co] * w[co][k] on the matrix cores, as 16 x 16 x 4 products (NP is a
+    // multiple of 16 for the common 3-channel 4 x 4 layer; 32-wide tiles would pad it by a third): wave v owns pixels
+    // 64 v .. 64 v + 63 (four 16-row tiles) and all ceil(NP / 16) column tiles; per 32-channel chunk its A values come
     // from the staged tile and its B values (lane = column, coalesced rows of w) straight from memory.
-    constexpr int NTN = (NP + 31) / 32;
+    constexpr int NTN = (NP + 15) / 16;
+    typedef float f32x4_acc __attribute__((ext_vector_type(4)));
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int r = lane & 31, hh = lane >> 5;
-    f32x16 macc[2][NTN];
+    const int r = lane & 15, kq = lane >> 4;
+    f32x4_acc macc[4][NTN];
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
+    for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
-      for (int nt = 0; nt < NTN; ++nt)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) macc[mt][nt][e] = 0.f;
-    for (int cc0 = 0; cc0 < Co; cc0 += CCH) {
-      __syncthreads();
+      for (int nt = 0; nt < NTN; ++nt) macc[mt][nt] = f32x4_acc{0.f, 0.f, 0.f, 0.f};
+    // the next chunk's values are fetched into registers while the matrix cores work on the current one
+    f32x4 pre[8];
+    auto fetch = [&](int cc0) __attribute__((always_inline)) {
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
         if (src[j] >= 0 && cc0 + 4 * (int)(threadIdx.x & 7) < Co) v = *reinterpret_cast<const f32x4*>(gy + src[j] + cc0);
-        *reinterpret_cast<f32x4*>(&stage[((threadIdx.x >> 3) + 32 * j) * LDS_ + 4 * (threadIdx.x & 7)]) = v;
+        pre[j] = v;
       }
-      float bfr[CCH / 2][NTN];
+    };
+    fetch(0);
+    for (int cc0 = 0; cc0 < Co; cc0 += CCH) {
+      __syncthreads();
 #pragma unroll
-      for (int j = 0; j < CCH / 2; ++j) {
-        const int co = cc0 + 2 * j + hh;
+      for (int j = 0; j < 8; ++j)
+        *reinterpret_cast<f32x4*>(&stage[((threadIdx.x >> 3) + 32 * j) * LDS_ + 4 * (threadIdx.x & 7)]) = pre[j];
+      float bfr[CCH / 4][NTN];
+#pragma unroll
+      for (int j = 0; j < CCH / 4; ++j) {
+        const int co = cc0 + 4 * j + kq;
 #pragma unroll
         for (int nt = 0; nt < NTN; ++nt) {
-          const int col = 32 * nt + r;
+          const int col = 16 * nt + r;
           bfr[j][nt] = (co < Co && col < NP) ? w[(size_t)co * NP + col] : 0.f;
         }
       }
+      if (cc0 + CCH < Co) fetch(cc0 + CCH);
       __syncthreads();
 #pragma unroll
-      for (int j = 0; j < CCH / 2; ++j) {
-        const float a0 = stage[(64 * wave + r) * LDS_ + 2 * j + hh];
-        const float a1 = stage[(64 * wave + 32 + r) * LDS_ + 2 * j + hh];
+      for (int j = 0; j < CCH / 4; ++j) {
+        float av[4];
 #pragma unroll
-        for (int nt = 0; nt < NTN; ++nt) {
-          macc[0][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bfr[j][nt], macc[0][nt], 0, 0, 0);
-          macc[1][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, bfr[j][nt], macc[1][nt], 0, 0, 0);
-        }
+        for (int mt = 0; mt < 4; ++mt) av[mt] = stage[(64 * wave + 16 * mt + r) * LDS_ + 4 * j + kq];
+#pragma unroll
+        for (int nt = 0; nt < NTN; ++nt)
+#pragma unroll
+          for (int mt = 0; mt < 4; ++mt)
+            macc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mt], bfr[j][nt], macc[mt][nt], 0, 0, 0);
       }
     }
     __syncthreads();
-    // accumulator element e of a lane is row (e & 3) + 8 (e >> 2) + 4 hh, column r of its 32 x 32 tile
+    // accumulator element e of a lane is row 4 kq + e, column r of its 16 x 16 tile
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
+    for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
       for (int nt = 0; nt < NTN; ++nt) {
-        const int col = 32 * nt + r;
+        const int col = 16 * nt + r;
         if (col < NP) {
 #pragma unroll
-          for (int e = 0; e < 16; ++e)
-            part[(64 * wave + 32 * mt + (e & 3) + 8 * (e >> 2) + 4 * hh) * LDP + col] = macc[mt][nt][e];
+          for (int e = 0; e < 4; ++e) part[(64 * wave + 16 * mt + 4 * kq + e) * LDP + col] = macc[mt][nt][e];
         }
       }
   } else if (mine) {
@@ -280,6 +289,55 @@ __global__ void __launch_bounds__(256) dgrad_scatter_kernel(const float* __restr
   for (int c = 0; c < CI; ++c) b[c] = bias ? bias[c] : 0.f;
   const int nth = (KH + sh - 1) / sh, ntw = (KW + sw - 1) / sw;
   const float inv_ow = 1.0f / (float)OW, inv_sh = 1.0f / (float)sh, inv_sw = 1.0f / (float)sw;
+  // sums the partials that land on output pixel (hi, wi), in tap order
+  auto gather = [&](int hi, int wi, float (&sum)[CI]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int c = 0; c < CI; ++c) sum[c] = b[c];
+    const int qh = vg_div_small(hi + ph, inv_sh), qw = vg_div_small(wi + pw, inv_sw);
+    for (int a = 0; a < nth; ++a) {
+      const int q = qh - a, kh = hi + ph - q * sh;
+      if (kh >= KH || q < 0) break;
+      const int ry = q - h0;
+      if (q >= Ho || (unsigned)ry >= (unsigned)RH) continue;
+      for (int bb = 0; bb < ntw; ++bb) {
+        const int v = qw - bb, kw = wi + pw - v * sw;
+        if (kw >= KW || v < 0) break;
+        const int rx = v - w0;
+        if (v >= Wo || (unsigned)rx >= (unsigned)RW) continue;
+        const float* pp = &part[(ry * RW + rx) * LDP + (kh * KW + kw) * CI];
+#pragma unroll
+        for (int c = 0; c < CI; ++c) sum[c] += pp[c];
+      }
+    }
+  };
+  if (tiles_w == 1) {
+    // The tile's output rows are whole image rows, adjacent in memory: 256 pixels per pass go through LDS and leave
+    // as consecutive floats on consecutive lanes (a lane storing its own pixel writes CI floats at a CI-float stride).
+    float* outbuf = part + 256 * LDP;
+    const int total = OH * OW;
+    for (int o0 = 0; o0 < total; o0 += 256) {
+      const int o = o0 + threadIdx.x;
+      const int oy = vg_div_small(o, inv_ow), ox = o - oy * OW;
+      const int hi = hi_lo + oy;
+      float sum[CI];
+#pragma unroll
+      for (int c = 0; c < CI; ++c) sum[c] = 0.f;
+      if (o < total && (unsigned)hi < (unsigned)H) gather(hi, ox, sum);
+#pragma unroll
+      for (int c = 0; c < CI; ++c) outbuf[threadIdx.x * CI + c] = sum[c];
+      __syncthreads();
+      float* dst = gx + ((long long)(n * H + hi_lo) * W + o0) * CI;
+#pragma unroll
+      for (int k = 0; k < CI; ++k) {
+        const int f = threadIdx.x + 256 * k;
+        const int oo = o0 + f / CI;
+        const int hh2 = hi_lo + vg_div_small(oo, inv_ow);
+        if (oo < total && (unsigned)hh2 < (unsigned)H) dst[f] = outbuf[f];
+      }
+      __syncthreads();
+    }
+    return;
+  }
   for (int o = threadIdx.x; o < OH * OW; o += 256) {
     const int oy = vg_div_small(o, inv_ow), ox = o - oy * OW;
     const int hi = hi_lo + oy, wi = wi_lo + ox;
@@ -542,7 +600,7 @@ static int try_dgrad_scatter(const vg_conv_geom* g, const float* gy, const float
     scatter_tiling(g->Ho, rh, nth, &th, &sh_, &oh);
     scatter_tiling(g->Wo, rw, ntw, &tw, &sw_, &ow);
     const long long blocks = (long long)th * tw;
-    if (best_rw == 0 || blocks < best_blocks) {
+    if (best_rw == 0 || blocks < best_blocks || (blocks == best_blocks && tw == 1)) {
       best_rw = rw; best_blocks = blocks; bt_h = th; bt_w = tw; bs_h = sh_; bs_w = sw_; bo_h = oh; bo_w = ow;
     }
   }
