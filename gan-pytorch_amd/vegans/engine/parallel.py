@@ -106,8 +106,15 @@ class GradReducer:
             cur_n += p.numel()
         if cur:
             self.buckets.append(cur)
-        self.flat = [torch.empty(sum(p.numel() for p in b), dtype=torch.float32, device=b[0].device)
-                     for b in self.buckets]
+        # the buckets are consecutive 256-byte aligned pieces of one buffer: eager iterations all-reduce them one by
+        # one as they fill up (overlapping backward), replayed iterations all-reduce the whole buffer in one collective
+        sizes = [sum(p.numel() for p in b) for b in self.buckets]
+        starts, end = [], 0
+        for n in sizes:
+            starts.append(end)
+            end += (n + 63) // 64 * 64
+        self.whole = torch.zeros(max(end, 1), dtype=torch.float32, device=order[0].device if order else "cpu")
+        self.flat = [self.whole[s0:s0 + n] for s0, n in zip(starts, sizes)]
         self.where = {}
         for bi, b in enumerate(self.buckets):
             off = 0
@@ -150,6 +157,8 @@ class GradReducer:
             # the iteration is being recorded into HIP graphs: nothing was launched from the hooks; cut the recording
             # here and let every replay all-reduce the buckets that received gradients, between two graph launches
             flats = [self.flat[bi] for bi, left in enumerate(self.pending) if left < len(self.buckets[bi])]
+            if len(flats) == len(self.flat) and len(flats) > 1:
+                flats = [self.whole]          # one collective instead of one per bucket (padding between them is zero)
             self.armed = False
             graph.cut(lambda: _all_reduce_now(flats))
             return
