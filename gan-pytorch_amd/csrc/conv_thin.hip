@@ -396,7 +396,8 @@ __global__ void __launch_bounds__(256) stem_fwd_kernel(const float* __restrict__
   constexpr int PWID = (TW - 1) * S + KK, PH = (TH - 1) * S + KK;   // patch extent in input pixels
   constexpr int ROWF = PWID * CI;                                   // floats per patch row
   constexpr int LDW = K | 1;                                        // odd weight row stride: conflict-free column reads
-  __shared__ float patch[PH * ROWF];
+  constexpr int PATCH = (PH * ROWF + 3) & ~3;
+  __shared__ float patch[2 * PATCH];
   __shared__ float wsm[64 * LDW];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r = lane & 31, h = lane >> 5;
@@ -421,6 +422,10 @@ __global__ void __launch_bounds__(256) stem_fwd_kernel(const float* __restrict__
   float bv[2];
 #pragma unroll
   for (int t = 0; t < 2; ++t) bv[t] = (bias && co0 + 32 * t + r < Co) ? bias[co0 + 32 * t + r] : 0.f;
+  // Pin the arrival of the bias values here. Their first use is inside the conditionally executed store blocks below;
+  // left there, every one of those blocks gets its own wait for all outstanding memory operations, which also waits
+  // for the store before it and serialises the stores.
+  asm volatile("" ::"v"(bv[0]), "v"(bv[1]));
 
   // patch element i of a thread: row pr, pixel px, channel pc (the same for every tile)
   constexpr int PPT = (PH * ROWF + 255) / 256;
@@ -445,25 +450,39 @@ __global__ void __launch_bounds__(256) stem_fwd_kernel(const float* __restrict__
 #pragma unroll
     for (int u = 0; u < PPT; ++u) {
       const int hi = hi0 + p_row[u], wi = wi0 + p_px[u];
-      pre[u] = ((unsigned)hi < (unsigned)H && (unsigned)wi < (unsigned)W) ? img[((size_t)hi * W + wi) * CI + p_c[u]] : 0.f;
+      // always a load from inside the image (clamped), zeroed afterwards: no branch around the load
+      const bool in = (unsigned)hi < (unsigned)H && (unsigned)wi < (unsigned)W;
+      const int hc = min(max(hi, 0), H - 1), wc = min(max(wi, 0), W - 1);
+      const float v = img[((size_t)hc * W + wc) * CI + p_c[u]];
+      pre[u] = in ? v : 0.f;
     }
   };
-  if ((int)blockIdx.x < tiles_total) fetch_patch(blockIdx.x);
-
+  // Two patch buffers. Per tile: the next tile's patch is requested, the matrix cores run on the current buffer, the
+  // arrived values go to the other buffer and only then are this tile's results stored. The stores thus drain under
+  // the next tile's products: the wait for the patch loads (the memory counter completes in order) falls behind them,
+  // where the previous tile's stores have long finished, instead of directly after a tile's own stores.
+  if ((int)blockIdx.x < tiles_total) {
+    fetch_patch(blockIdx.x);
+#pragma unroll
+    for (int u = 0; u < PPT; ++u) {
+      const int i = threadIdx.x + 256 * u;
+      if (i < PH * ROWF) patch[i] = pre[u];
+    }
+  }
+  __syncthreads();
+  // the activation as two uniform values, so that the store loop below stays free of branches on `act`:
+  // non-positive results are multiplied by `neg` (1: no activation) or, for ReLU, replaced by 0
+  const bool relu = act == VG_ACT_RELU;
+  const float neg = act == VG_ACT_LRELU ? slope : 1.f;
+  int cur = 0;
   for (int tile = blockIdx.x; tile < tiles_total; tile += gridDim.x) {
     int bid = tile;
     const int tw = bid % tiles_w; bid /= tiles_w;
     const int th = bid % tiles_h;
     const int n = bid / tiles_h;
     const int ho0 = th * TH, wo0 = tw * TW;
-    __syncthreads();      // the previous tile's reads are done
-#pragma unroll
-    for (int u = 0; u < PPT; ++u) {
-      const int i = threadIdx.x + 256 * u;
-      if (i < PH * ROWF) patch[i] = pre[u];
-    }
-    __syncthreads();
-    if (tile + (int)gridDim.x < tiles_total) fetch_patch(tile + gridDim.x);   // in flight under the MFMAs below
+    const bool more = tile + (int)gridDim.x < tiles_total;
+    if (more) fetch_patch(tile + gridDim.x);   // in flight under the MFMAs below
 
     f32x16 acc[2];
 #pragma unroll
@@ -471,7 +490,7 @@ __global__ void __launch_bounds__(256) stem_fwd_kernel(const float* __restrict__
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
     // A[pixel r of this wave's row][k] = patch[(wave*S + kh) * ROWF + (r*S + kw) * CI + ci], k = (kh*KK + kw)*CI + ci
-    const float* base = patch + wave * S * ROWF + r * S * CI;
+    const float* base = patch + cur * PATCH + wave * S * ROWF + r * S * CI;
 #pragma unroll
     for (int j = 0; j < KP; ++j) {
       constexpr int KC = KK * CI;
@@ -483,22 +502,39 @@ __global__ void __launch_bounds__(256) stem_fwd_kernel(const float* __restrict__
       acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bw[0][j], acc[0], 0, 0, 0);
       acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bw[1][j], acc[1], 0, 0, 0);
     }
-    const int ho = ho0 + wave;
-    if (ho < Ho) {
+    if (more) {
+      float* nxt = patch + (cur ^ 1) * PATCH;
 #pragma unroll
-      for (int t = 0; t < 2; ++t) {
-        if (t == 1 && !two) break;
-        const int co = co0 + 32 * t + r;
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          const int wo = wo0 + (e & 3) + 8 * (e >> 2) + 4 * h;
-          float v = acc[t][e] + bv[t];
-          if (act == VG_ACT_RELU) v = v > 0.f ? v : 0.f;
-          else if (act == VG_ACT_LRELU) v = v > 0.f ? v : v * slope;
-          if (wo < Wo) y[((size_t)(n * Ho + ho) * Wo + wo) * Co + co] = v;
-        }
+      for (int u = 0; u < PPT; ++u) {
+        const int i = threadIdx.x + 256 * u;
+        if (i < PH * ROWF) nxt[i] = pre[u];
       }
     }
+    const int ho = ho0 + wave;
+    if (ho < Ho) {
+      // lane (r, h) owns channel co0 + 32 t + r of pixels wo0 + 4 h + {0..3} + 8 g: one 64-bit base per tile, then
+      // offsets that are compile-time multiples of Co
+      float* yb = y + ((size_t)(n * Ho + ho) * Wo + wo0 + 4 * h) * Co + co0 + r;
+      auto put = [&](auto checked) __attribute__((always_inline)) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          if (t == 1 && !two) break;
+#pragma unroll
+          for (int e = 0; e < 16; ++e) {
+            const int px = (e & 3) + 8 * (e >> 2);
+            float v = acc[t][e] + bv[t];
+            const float lo = relu ? 0.f : v * neg;
+            v = v > 0.f ? v : lo;
+            if (!decltype(checked)::value || wo0 + 4 * h + px < Wo) yb[px * Co + 32 * t] = v;
+          }
+        }
+      };
+      // uniform: when no pixel of the tile lies beyond the row the stores carry no conditions at all
+      if (wo0 + TW <= Wo) put(std::false_type{});
+      else put(std::true_type{});
+    }
+    __syncthreads();      // the other buffer is complete, this one is free
+    cur ^= 1;
   }
 }
 
@@ -508,8 +544,10 @@ int try_fwd_stem(const vg_conv_geom* g, const float* x, const float* w, const fl
   const int tiles_w = (g->Wo + 31) / 32, tiles_h = (g->Ho + 3) / 4;
   const long long blocks = (long long)tiles_w * tiles_h * g->N;
   if (blocks > 0x7fffffffLL) return 0;
-  // a block keeps its weight fragments in registers and walks tiles: about four blocks per CU
-  dim3 grid((unsigned)(blocks < 1024 ? blocks : 1024), (unsigned)((g->Co + 63) / 64));
+  // a block keeps its weight fragments in registers and walks tiles, a tile's stores draining under the next tile's
+  // products: two blocks per CU, so that every block sees several tiles
+  const long long cap = 512;
+  dim3 grid((unsigned)(blocks < cap ? blocks : cap), (unsigned)((g->Co + 63) / 64));
   bool done = false;
 #define STEM_FWD(CI_, KK_, S_)                                                                                          \
   if (!done && g->Ci == CI_ && g->kh == KK_ && g->sh == S_) {                                                          \
