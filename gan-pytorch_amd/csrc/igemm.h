@@ -622,29 +622,55 @@ __global__ void __launch_bounds__(NW * 64) igemm_kernel(const IgemmParams p) {
   // ---- epilogue: lane holds column (lane&31) and rows (e&3)+8*(e>>2)+4*(lane>>5) of each 32x32 tile ----
   float* outp = p.out;
   if constexpr (MODE == MODE_WGRAD) outp += (size_t)zz * p.slab_stride;
+  // Per column tile: validity and the bias value, fetched once and pinned here. A load whose first use sits inside the
+  // conditionally executed store blocks below gives every one of them its own wait for all outstanding memory
+  // operations, which also waits for the store before it: the stores of a tile would leave one by one.
+  bool cok[TN];
+  float bcol[TN];
+  bool has_bias = false;
 #pragma unroll
-  for (int mi = 0; mi < TM; ++mi) {
-#pragma unroll
-    for (int e = 0; e < 16; ++e) {
-      const int row = m0 + (wm * TM + mi) * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-      if (row >= M) continue;
-      size_t rowoff;
-      if constexpr (MODE == MODE_DGRAD) {
-        const int n = vg_div_row(row, plane, inv_plane, fast), rem = row - n * plane;
-        const int ii = vg_div_row(rem, roww, inv_roww, fast), jj = rem - ii * roww;
-        rowoff = (size_t)((n * p.H + ii * p.sh + off_h) * p.W + jj * p.sw + off_w) * p.Ncols;
-      } else {
-        rowoff = (size_t)row * p.Ncols;
-      }
+  for (int ni = 0; ni < TN; ++ni) {
+    const int col = n0 + (wn * TN + ni) * 32 + r;
+    cok[ni] = col < p.Ncols;
+    bcol[ni] = 0.f;
+  }
+  if constexpr (MODE != MODE_WGRAD) {
+    has_bias = p.bias != nullptr;
+    if (has_bias) {
 #pragma unroll
       for (int ni = 0; ni < TN; ++ni) {
         const int col = n0 + (wn * TN + ni) * 32 + r;
-        if (col < p.Ncols) {
+        if (cok[ni]) bcol[ni] = p.bias[col % p.bias_mod];
+      }
+#pragma unroll
+      for (int ni = 0; ni < TN; ++ni) asm volatile("" ::"v"(bcol[ni]));
+    }
+  }
+  float* colp = outp + n0 + wn * TN * 32 + r;
+#pragma unroll
+  for (int mi = 0; mi < TM; ++mi) {
+    const int row_t = m0 + (wm * TM + mi) * 32 + 4 * h;      // first of the lane's 16 rows of this tile
+    float* tilep = colp;
+    if constexpr (MODE != MODE_DGRAD) tilep += (size_t)row_t * p.Ncols;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int dr = (e & 3) + 8 * (e >> 2);
+      const int row = row_t + dr;
+      if (row >= M) continue;
+      float* rp;
+      if constexpr (MODE == MODE_DGRAD) {
+        const int n = vg_div_row(row, plane, inv_plane, fast), rem = row - n * plane;
+        const int ii = vg_div_row(rem, roww, inv_roww, fast), jj = rem - ii * roww;
+        rp = tilep + (size_t)((n * p.H + ii * p.sh + off_h) * p.W + jj * p.sw + off_w) * p.Ncols;
+      } else {
+        rp = tilep + dr * p.Ncols;
+      }
+#pragma unroll
+      for (int ni = 0; ni < TN; ++ni) {
+        if (cok[ni]) {
           float v = acc[mi][ni][e];
-          if constexpr (MODE != MODE_WGRAD) {
-            if (p.bias) v += p.bias[col % p.bias_mod];
-          }
-          outp[rowoff + col] = v;
+          if (has_bias) v += bcol[ni];
+          rp[ni * 32] = v;
         }
       }
     }
