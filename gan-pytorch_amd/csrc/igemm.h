@@ -252,6 +252,12 @@ __global__ void __launch_bounds__(NW * 64) igemm_kernel(const IgemmParams p) {
     return *reinterpret_cast<const f32x4*>(ptr);
   };
 
+  // the same for the 4-byte loads of operands that cannot be read as vectors (3-channel images, odd channel counts)
+  auto ld1 = [&](const float* base, size_t off, bool ok) -> float {
+    const float* ptr = ok ? base + off : vg_zero_page;
+    return *ptr;
+  };
+
   auto load_tiles = [&]() {
     const int kb = kpos;
     // ---------------- A ----------------
@@ -292,12 +298,12 @@ __global__ void __launch_bounds__(NW * 64) igemm_kernel(const IgemmParams p) {
           for (int e = 0; e < 4; ++e) {
             if constexpr (MODE == MODE_FWD) {
               const int hi = a_h[i] + ta[e], wi = a_w[i] + tb[e];
-              if (kv[e] && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W)
-                v[e] = p.A[(size_t)(a_img[i] + hi * p.W + wi) * p.Ci + c[e]];
+              v[e] = ld1(p.A, (size_t)(a_img[i] + hi * p.W + wi) * p.Ci + c[e],
+                         kv[e] && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W);
             } else {
               const int ho = a_h[i] - ta[e], wo = a_w[i] - tb[e];
-              if (kv[e] && (unsigned)ho < (unsigned)p.Ho && (unsigned)wo < (unsigned)p.Wo)
-                v[e] = p.A[(size_t)(a_img[i] + ho * p.Wo + wo) * p.Co + c[e]];
+              v[e] = ld1(p.A, (size_t)(a_img[i] + ho * p.Wo + wo) * p.Co + c[e],
+                         kv[e] && (unsigned)ho < (unsigned)p.Ho && (unsigned)wo < (unsigned)p.Wo);
             }
           }
           ra[i] = v;
@@ -312,12 +318,9 @@ __global__ void __launch_bounds__(NW * 64) igemm_kernel(const IgemmParams p) {
         if constexpr (VA == 4) {
           ra[i] = ld4(p.A, (size_t)pix * p.Co + m4, pix < kend && m4 < p.Co);
         } else {
-          f32x4 v = zero4;
-          if (pix < kend) {
+          f32x4 v;
 #pragma unroll
-            for (int e = 0; e < 4; ++e)
-              if (m4 + e < p.Co) v[e] = p.A[(size_t)pix * p.Co + m4 + e];
-          }
+          for (int e = 0; e < 4; ++e) v[e] = ld1(p.A, (size_t)pix * p.Co + m4 + e, pix < kend && m4 + e < p.Co);
           ra[i] = v;
         }
       }
@@ -332,12 +335,9 @@ __global__ void __launch_bounds__(NW * 64) igemm_kernel(const IgemmParams p) {
         if constexpr (VB == 4) {
           rb[i] = ld4(p.B, (size_t)n * Ktot + k4, n < p.Ncols && k4 < kend);
         } else {
-          f32x4 v = zero4;
-          if (n < p.Ncols) {
+          f32x4 v;
 #pragma unroll
-            for (int e = 0; e < 4; ++e)
-              if (k4 + e < kend) v[e] = p.B[(size_t)n * Ktot + k4 + e];
-          }
+          for (int e = 0; e < 4; ++e) v[e] = ld1(p.B, (size_t)n * Ktot + k4 + e, n < p.Ncols && k4 + e < kend);
           rb[i] = v;
         }
       }
@@ -349,12 +349,9 @@ __global__ void __launch_bounds__(NW * 64) igemm_kernel(const IgemmParams p) {
         if constexpr (VB == 4) {
           rb[i] = ld4(p.B, (size_t)k * p.Ncols + bn4, k < kend && bn4 < p.Ncols);
         } else {
-          f32x4 v = zero4;
-          if (k < kend) {
+          f32x4 v;
 #pragma unroll
-            for (int e = 0; e < 4; ++e)
-              if (bn4 + e < p.Ncols) v[e] = p.B[(size_t)k * p.Ncols + bn4 + e];
-          }
+          for (int e = 0; e < 4; ++e) v[e] = ld1(p.B, (size_t)k * p.Ncols + bn4 + e, k < kend && bn4 + e < p.Ncols);
           rb[i] = v;
         }
       }
@@ -369,12 +366,9 @@ __global__ void __launch_bounds__(NW * 64) igemm_kernel(const IgemmParams p) {
         if constexpr (VB == 4) {
           rb[i] = ld4(p.B, base + bn4, k < kend && bn4 < p.Ncols);
         } else {
-          f32x4 v = zero4;
-          if (k < kend) {
+          f32x4 v;
 #pragma unroll
-            for (int e = 0; e < 4; ++e)
-              if (bn4 + e < p.Ncols) v[e] = p.B[base + bn4 + e];
-          }
+          for (int e = 0; e < 4; ++e) v[e] = ld1(p.B, base + bn4 + e, k < kend && bn4 + e < p.Ncols);
           rb[i] = v;
         }
       }
@@ -390,14 +384,12 @@ __global__ void __launch_bounds__(NW * 64) igemm_kernel(const IgemmParams p) {
           const bool ok = pix < kend && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
           rb[i] = ld4(p.B, (size_t)((bpn * p.H + hi) * p.W + wi) * p.Ci + b_ci[0], ok);
         } else {
-          f32x4 v = zero4;
-          if (pix < kend) {
+          f32x4 v;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              const int hi = hb + b_ta[e], wi = wb + b_tb[e];
-              if ((unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W)
-                v[e] = p.B[(size_t)((bpn * p.H + hi) * p.W + wi) * p.Ci + b_ci[e]];
-            }
+          for (int e = 0; e < 4; ++e) {
+            const int hi = hb + b_ta[e], wi = wb + b_tb[e];
+            v[e] = ld1(p.B, (size_t)((bpn * p.H + hi) * p.W + wi) * p.Ci + b_ci[e],
+                       pix < kend && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W);
           }
           rb[i] = v;
         }
