@@ -49,10 +49,29 @@ __global__ void __launch_bounds__(256) slab_reduce_kernel(const float* __restric
   f32x4 a = {0.f, 0.f, 0.f, 0.f};
   if (i < ncols) {
     if (vec) {
-      const f32x4* s4 = reinterpret_cast<const f32x4*>(slabs);
-      for (int z = lane; z < nsplit; z += LANES) a += s4[(size_t)z * ncols + i];
+      // eight loads in flight, added in slab order (the sum's order is what makes the result reproducible; issued
+      // one at a time the loop is a chain of memory latencies)
+      const f32x4* s4 = reinterpret_cast<const f32x4*>(slabs) + i;
+      int z = lane;
+      for (; z + 7 * LANES < nsplit; z += 8 * LANES) {
+        f32x4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = s4[(size_t)(z + u * LANES) * ncols];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) a += v[u];
+      }
+      for (; z < nsplit; z += LANES) a += s4[(size_t)z * ncols];
     } else {
-      for (int z = lane; z < nsplit; z += LANES) a[0] += slabs[(size_t)z * count + i];
+      const float* s1 = slabs + i;
+      int z = lane;
+      for (; z + 7 * LANES < nsplit; z += 8 * LANES) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = s1[(size_t)(z + u * LANES) * count];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) a[0] += v[u];
+      }
+      for (; z < nsplit; z += LANES) a[0] += s1[(size_t)z * count];
     }
   }
   if constexpr (LANES > 1) {
