@@ -20,6 +20,7 @@ int vg_check_geom(const vg_conv_geom* g, const char* who) {
 int vg_try_fwd_thin(const vg_conv_geom* g, const float* x, const float* w, const float* bias, float* y, hipStream_t st);
 int vg_thin_dgrad_applies(const vg_conv_geom* g);
 int vg_stem_fwd_applies(const vg_conv_geom* g);
+int vg_stem_wgrad_applies(const vg_conv_geom* g);
 
 static int check_precision(int precision, const char* who) {
   if (precision < VG_PREC_F32 || precision > VG_PREC_F32_SPLIT) return vg_fail(VG_ERR_INVALID, "%s: unknown precision %d", who, precision);
@@ -131,6 +132,10 @@ extern "C" int vg_conv2d_variant(int mode, const vg_conv_geom* g, char* buf, siz
   }
   if (mode == 0 && vg_stem_fwd_applies(g)) {
     snprintf(buf, len, "stem_fwd_kernel<%d, %d, %d>", g->Ci, g->kh, g->sh);
+    return VG_OK;
+  }
+  if (mode == 2 && vg_stem_wgrad_applies(g) && rows >= 512) {     // (more than one split-K slab)
+    snprintf(buf, len, "stem_wgrad_kernel<%d, %d, %d>", g->Ci, g->kh, g->sh);
     return VG_OK;
   }
   const bool gemm_dgrad = g->Ho == 1 && g->Wo == 1 && g->ph == 0 && g->pw == 0 && g->H == g->kh && g->W == g->kw;

@@ -450,11 +450,10 @@ __global__ void __launch_bounds__(256) stem_fwd_kernel(const float* __restrict__
 #pragma unroll
     for (int u = 0; u < PPT; ++u) {
       const int hi = hi0 + p_row[u], wi = wi0 + p_px[u];
-      // always a load from inside the image (clamped), zeroed afterwards: no branch around the load
+      // no branch around the load and no use of the loaded value here: a lane outside the image reads the zero page
       const bool in = (unsigned)hi < (unsigned)H && (unsigned)wi < (unsigned)W;
-      const int hc = min(max(hi, 0), H - 1), wc = min(max(wi, 0), W - 1);
-      const float v = img[((size_t)hc * W + wc) * CI + p_c[u]];
-      pre[u] = in ? v : 0.f;
+      const float* ptr = in ? img + ((size_t)hi * W + wi) * CI + p_c[u] : vg_zero_page;
+      pre[u] = *ptr;
     }
   };
   // Two patch buffers. Per tile: the next tile's patch is requested, the matrix cores run on the current buffer, the
@@ -538,6 +537,148 @@ __global__ void __launch_bounds__(256) stem_fwd_kernel(const float* __restrict__
   }
 }
 
+// Weight gradient of an image stem (the layers stem_fwd_kernel serves, output channels in multiples of 64):
+// gw[co][k] = sum over output pixels of gy[pixel][co] * patch[pixel][k], K = KK*KK*CI a few dozen. The generic
+// implicit GEMM gathers the patch operand with one 4-byte load per element; here the input patch of a tile of output
+// pixels is staged in LDS exactly as in the forward kernel and read from there as the B operand of 16 x 16 x 4
+// products (lane = column k, four consecutive pixels of the wave's row), while the A operand comes straight from
+// memory: lane (i, q) reads the 16 bytes gy[pixel 4 j + q][co0 + 4 i .. + 3], whose element m feeds row tile m, so row
+// i of tile m is channel co0 + 4 i + m and a wave's load covers whole 256-byte pixel rows. A block (4 waves, wave v =
+// row v of a 4 x 32 pixel tile) walks tiles blockIdx.x, blockIdx.x + gridDim.x, ... with the next tile's operands in
+// flight, keeps its 64 x K partial result in registers, adds the four waves' parts in wave order through LDS and writes
+// one slab; the slabs are then added in slab order by the split-K reduce of the generic path (same layout and count).
+template <int CI, int KK, int S>
+__global__ void __launch_bounds__(256) stem_wgrad_kernel(const float* __restrict__ gy, const float* __restrict__ x,
+                                                         float* __restrict__ slabs, int H, int W, int Co, int Ho, int Wo,
+                                                         int ph, int pw, int tiles_w, int tiles_h, int tiles_total) {
+  constexpr int K = KK * KK * CI, NT = (K + 15) / 16, KC = KK * CI;
+  constexpr int TW = 32, TH = 4;
+  constexpr int PWID = (TW - 1) * S + KK, PH = (TH - 1) * S + KK;
+  constexpr int ROWF = PWID * CI;
+  constexpr int PATCH = (PH * ROWF + 3) & ~3;
+  typedef float f32x4_acc __attribute__((ext_vector_type(4)));
+  __shared__ float patch[2 * PATCH];
+  __shared__ float red[4 * 64 * K];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int i16 = lane & 15, q = lane >> 4;
+  const int co0 = blockIdx.y * 64;
+
+  // column k = 16 nt + i16 of this lane: offset of its patch element relative to the pixel's window origin
+  int offc[NT];
+  bool cok[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    const int c = 16 * nt + i16;
+    cok[nt] = c < K;
+    const int cc = cok[nt] ? c : 0;
+    offc[nt] = (cc / KC) * ROWF + (cc % KC);
+  }
+
+  constexpr int PPT = (PH * ROWF + 255) / 256;
+  int p_row[PPT], p_px[PPT], p_c[PPT];
+#pragma unroll
+  for (int u = 0; u < PPT; ++u) {
+    const int i = threadIdx.x + 256 * u;
+    p_row[u] = i / ROWF;
+    const int pc = i - p_row[u] * ROWF;
+    p_px[u] = pc / CI;
+    p_c[u] = pc - p_px[u] * CI;
+    if (i >= PH * ROWF) p_row[u] = -(1 << 28);
+  }
+  float pre[PPT];
+  f32x4 nxt[8];
+  // requests the operands of `tile`: its input patch (zero where the window leaves the image) and this lane's gy values
+  auto fetch = [&](int tile) __attribute__((always_inline)) {
+    int bid = tile;
+    const int tw = bid % tiles_w; bid /= tiles_w;
+    const int th = bid % tiles_h;
+    const int n = bid / tiles_h;
+    const int ho = th * TH + wave, wo0 = tw * TW;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int wo = wo0 + 4 * j + q;
+      // an invalid lane reads the zero page: the loaded value itself is not touched, so nothing waits for it here
+      const bool ok = ho < Ho && wo < Wo;
+      const float* ptr = ok ? gy + ((size_t)(n * Ho + ho) * Wo + wo) * Co + co0 + 4 * i16 : vg_zero_page;
+      nxt[j] = *reinterpret_cast<const f32x4*>(ptr);
+    }
+    const int hi0 = th * TH * S - ph, wi0 = tw * TW * S - pw;
+    const float* img = x + (size_t)n * H * W * CI;
+#pragma unroll
+    for (int u = 0; u < PPT; ++u) {
+      const int hi = hi0 + p_row[u], wi = wi0 + p_px[u];
+      const bool in = (unsigned)hi < (unsigned)H && (unsigned)wi < (unsigned)W;
+      const float* ptr = in ? img + ((size_t)hi * W + wi) * CI + p_c[u] : vg_zero_page;
+      pre[u] = *ptr;
+    }
+  };
+
+  f32x4_acc acc[4][NT];
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4_acc{0.f, 0.f, 0.f, 0.f};
+
+  if ((int)blockIdx.x < tiles_total) {
+    fetch(blockIdx.x);
+#pragma unroll
+    for (int u = 0; u < PPT; ++u) {
+      const int i = threadIdx.x + 256 * u;
+      if (i < PH * ROWF) patch[i] = pre[u];
+    }
+  }
+  __syncthreads();
+  int cur = 0;
+  for (int tile = blockIdx.x; tile < tiles_total; tile += gridDim.x) {
+    f32x4 a[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) a[j] = nxt[j];
+    const bool more = tile + (int)gridDim.x < tiles_total;
+    if (more) fetch(tile + gridDim.x);       // in flight under the products below
+    const float* base = patch + cur * PATCH + wave * S * ROWF + q * S * CI;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float b[NT];
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const float v = base[offc[nt] + 4 * j * S * CI];
+        b[nt] = cok[nt] ? v : 0.f;
+      }
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+          acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j][mt], b[nt], acc[mt][nt], 0, 0, 0);
+    }
+    if (more) {
+      float* other = patch + (cur ^ 1) * PATCH;
+#pragma unroll
+      for (int u = 0; u < PPT; ++u) {
+        const int i = threadIdx.x + 256 * u;
+        if (i < PH * ROWF) other[i] = pre[u];
+      }
+    }
+    __syncthreads();
+    cur ^= 1;
+  }
+
+  // The four waves' parts go to LDS side by side (element e of a lane is row 4 q + e, column i16 of its 16 x 16 tile);
+  // then every thread adds the four parts of its elements in wave order and writes them to the slab.
+  float* mine = red + wave * (64 * K);
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      if (!cok[nt]) continue;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) mine[(4 * (4 * q + e) + mt) * K + 16 * nt + i16] = acc[mt][nt][e];
+    }
+  __syncthreads();
+  float* slab = slabs + ((size_t)blockIdx.x * Co + co0) * K;
+  for (int i = threadIdx.x; i < 64 * K; i += 256)
+    slab[i] = ((red[i] + red[64 * K + i]) + red[2 * 64 * K + i]) + red[3 * 64 * K + i];
+}
+
 int try_fwd_stem(const vg_conv_geom* g, const float* x, const float* w, const float* bias, float* y, hipStream_t st,
                  int act, float slope) {
   if (!vg_stem_fwd_applies(g)) return 0;
@@ -564,6 +705,33 @@ int try_fwd_stem(const vg_conv_geom* g, const float* x, const float* w, const fl
 }
 
 }  // namespace
+
+// Stem weight gradient into `nslabs` slabs of [Co][K] floats (the generic split-K layout); 1 if taken, 0 if the shape
+// does not qualify, < 0 on error.
+int vg_stem_wgrad_applies(const vg_conv_geom* g) {
+  return vg_stem_fwd_applies(g) && g->Co % 64 == 0 && g->kh == g->kw && g->sh == g->sw;
+}
+
+int vg_try_wgrad_stem(const vg_conv_geom* g, const float* gy, const float* x, float* slabs, int nslabs, hipStream_t st) {
+  if (!vg_stem_wgrad_applies(g) || nslabs < 2 || !vg_aligned16(gy)) return 0;
+  const int tiles_w = (g->Wo + 31) / 32, tiles_h = (g->Ho + 3) / 4;
+  const long long tiles = (long long)tiles_w * tiles_h * g->N;
+  if (tiles > 0x7fffffffLL) return 0;
+  dim3 grid((unsigned)nslabs, (unsigned)(g->Co / 64));
+  bool done = false;
+#define STEM_WGRAD(CI_, KK_, S_)                                                                                       \
+  if (!done && g->Ci == CI_ && g->kh == KK_ && g->sh == S_) {                                                          \
+    hipLaunchKernelGGL((stem_wgrad_kernel<CI_, KK_, S_>), grid, dim3(256), 0, st, gy, x, slabs, g->H, g->W, g->Co,      \
+                       g->Ho, g->Wo, g->ph, g->pw, tiles_w, tiles_h, (int)tiles);                                      \
+    done = true;                                                                                                       \
+  }
+  STEM_WGRAD(3, 4, 2) STEM_WGRAD(1, 4, 2) STEM_WGRAD(3, 3, 1) STEM_WGRAD(1, 3, 1) STEM_WGRAD(3, 5, 2) STEM_WGRAD(1, 5, 2)
+#undef STEM_WGRAD
+  if (!done) return 0;
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return vg_fail(VG_ERR_LAUNCH, "vg_conv2d_wgrad(stem): launch failed: %s", hipGetErrorString(e));
+  return 1;
+}
 
 // Stem forward with ReLU / LeakyReLU applied to the result before it is stored; 0 when the stem kernel does not apply.
 int vg_try_fwd_stem_act(const vg_conv_geom* g, const float* x, const float* w, const float* bias, float* y, int act,

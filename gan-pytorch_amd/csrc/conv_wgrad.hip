@@ -3,6 +3,8 @@
 // its own f32 slab and a second kernel adds the slabs in split order (bitwise reproducible, no atomics).
 #include "pgemm.h"
 
+int vg_try_wgrad_stem(const vg_conv_geom* g, const float* gy, const float* x, float* slabs, int nslabs, hipStream_t st);
+
 namespace {
 
 struct WgradPlan {
@@ -150,6 +152,11 @@ extern "C" int vg_conv2d_wgrad_partial_prec(const vg_conv_geom* g, const float* 
   if (need > 0 && (!workspace || workspace_bytes < need || !vg_aligned16(workspace)))
     return vg_fail(VG_ERR_WORKSPACE, "vg_conv2d_wgrad: workspace of %zu bytes (16-byte aligned) required, got %zu",
                    need, workspace_bytes);
+
+  // image stems (3 or 1 input channels) have a kernel of their own that fills the same slabs
+  if (pl.nsplit > 1) {
+    if (int r = vg_try_wgrad_stem(g, gy, x, (float*)workspace, pl.nsplit, (hipStream_t)stream)) return r < 0 ? r : VG_OK;
+  }
 
   IgemmParams p{};
   p.A = gy; p.B = x; p.bias = nullptr;

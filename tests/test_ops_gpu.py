@@ -39,6 +39,8 @@ CONV_CASES = [
     (3, 1, 12, 12, 32, 5, 2, 2),     # stem kernel, Ci=1, 5x5 stride 2, ragged tile (6 x 6 outputs), one channel tile
     (2, 3, 9, 7, 96, 3, 1, 1),       # stem kernel, 3x3 stride 1 (odd K = 27), 96 channels: second grid row half filled
     (5, 1, 21, 70, 64, 4, 2, 1),     # stem kernel, Ci=1, several column tiles with a ragged last one
+    (6, 3, 11, 9, 128, 3, 1, 1),     # stem weight-gradient kernel: odd K = 27, two channel tiles, ragged pixel tiles
+    (3, 1, 30, 30, 64, 5, 2, 2),     # stem weight-gradient kernel: Ci=1, 5x5 stride 2, more slabs than tiles
 ]
 
 
