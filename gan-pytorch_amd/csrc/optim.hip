@@ -76,10 +76,11 @@ __global__ void __launch_bounds__(256) rmsprop_kernel(float* __restrict__ param,
     rmsprop_update<VEC>(param, grad, sq, mbuf, gavg, i, c, do_clamp);
 }
 
-// Many tensors, one launch: block b works on one 8192-element chunk of one tensor (first_block[] is the running
+// Many tensors, one launch: block b works on one 2048-element chunk of one tensor (two 16-byte groups per thread: with
+// 8192 the few hundred blocks of a DCGAN network left the chip latency-bound) (first_block[] is the running
 // count of chunks). A network's update is otherwise a dozen launches of a few microseconds each.
 constexpr int kMultiMax = 24;
-constexpr int kMultiChunk = 8192;
+constexpr int kMultiChunk = 2048;
 struct RmspropMulti {
   float* param[kMultiMax];
   const float* grad[kMultiMax];
