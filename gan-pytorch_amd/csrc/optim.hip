@@ -203,6 +203,51 @@ __global__ void __launch_bounds__(256) adam_multi_kernel(AdamMulti t, vg_adam_cf
   }
 }
 
+// Gradient accumulation owned by the engine: out = scale * (((src0 + src1) + src2) + ...), the sources added left to
+// right in the order the host lists them (the order is part of the result in floating point). One launch serves many
+// tensors, laid out over blocks like the optimizer kernels above; `out` may be one of the sources.
+constexpr int kSumMaxSrc = 8;
+struct GradSumMulti {
+  float* out[kMultiMax];
+  const float* src[kMultiMax][kSumMaxSrc];
+  unsigned long long n[kMultiMax];
+  float scale[kMultiMax];
+  int first_block[kMultiMax + 1];
+  int nsrc[kMultiMax];
+  int vec[kMultiMax];
+  int count;
+};
+
+__global__ void __launch_bounds__(256) grad_sum_multi_kernel(GradSumMulti t) {
+  int k = 0;
+  while (k + 1 < t.count && (int)blockIdx.x >= t.first_block[k + 1]) ++k;    // block-uniform
+  const size_t e0 = (size_t)((int)blockIdx.x - t.first_block[k]) * kMultiChunk;
+  const size_t e1 = e0 + kMultiChunk < t.n[k] ? e0 + kMultiChunk : (size_t)t.n[k];
+  const int ns = t.nsrc[k];
+  const float scale = t.scale[k];
+  if (t.vec[k]) {
+    for (size_t i = e0 / 4 + threadIdx.x; i < e1 / 4; i += 256) {
+      f32x4 v[kSumMaxSrc];
+#pragma unroll
+      for (int s = 0; s < kSumMaxSrc; ++s)
+        if (s < ns) v[s] = reinterpret_cast<const f32x4*>(t.src[k][s])[i];
+      f32x4 a = v[0];
+#pragma unroll
+      for (int s = 1; s < kSumMaxSrc; ++s)
+        if (s < ns) a += v[s];
+      if (scale != 1.f) a *= scale;
+      reinterpret_cast<f32x4*>(t.out[k])[i] = a;
+    }
+  } else {
+    for (size_t i = e0 + threadIdx.x; i < e1; i += 256) {
+      float a = t.src[k][0][i];
+      for (int s = 1; s < ns; ++s) a += t.src[k][s][i];
+      if (scale != 1.f) a *= scale;
+      t.out[k][i] = a;
+    }
+  }
+}
+
 __global__ void __launch_bounds__(256) sgd_kernel(float* __restrict__ param, const float* __restrict__ grad,
                                                   float* __restrict__ mbuf, size_t n, vg_sgd_cfg c) {
   const size_t stride = (size_t)gridDim.x * blockDim.x;
@@ -328,6 +373,39 @@ extern "C" int vg_adam_step_multi(int count, float* const* params, const float* 
     t.first_block[t.count] = blocks;
     hipLaunchKernelGGL(adam_multi_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, t, *cfg);
     VG_CHECK_LAUNCH("vg_adam_step_multi");
+  }
+  return VG_OK;
+}
+
+extern "C" int vg_grad_sum_multi(int count, float* const* outs, const float* const* srcs, const int* nsrc, const size_t* n,
+                                 const float* scales, void* stream) {
+  VG_REQUIRE(count > 0 && outs && srcs && nsrc && n && scales, "vg_grad_sum_multi: bad arguments");
+  for (int base = 0; base < count; base += kMultiMax) {
+    GradSumMulti t;
+    t.count = count - base < kMultiMax ? count - base : kMultiMax;
+    int blocks = 0;
+    for (int k = 0; k < t.count; ++k) {
+      const int j = base + k;
+      VG_REQUIRE(outs[j] && n[j] > 0 && nsrc[j] >= 1 && nsrc[j] <= kSumMaxSrc,
+                 "vg_grad_sum_multi: tensor %d: null output, empty tensor or source count outside 1..%d", j, kSumMaxSrc);
+      t.out[k] = outs[j];
+      bool vec = n[j] % 4 == 0 && vg_aligned16(outs[j]);
+      for (int s = 0; s < kSumMaxSrc; ++s) {
+        const float* p = s < nsrc[j] ? srcs[(size_t)j * kSumMaxSrc + s] : nullptr;
+        VG_REQUIRE(s >= nsrc[j] || p, "vg_grad_sum_multi: tensor %d: null source %d", j, s);
+        t.src[k][s] = p;
+        vec = vec && (!p || vg_aligned16(p));
+      }
+      t.n[k] = n[j];
+      t.nsrc[k] = nsrc[j];
+      t.scale[k] = scales[j];
+      t.vec[k] = vec ? 1 : 0;
+      t.first_block[k] = blocks;
+      blocks += (int)((n[j] + kMultiChunk - 1) / kMultiChunk);
+    }
+    t.first_block[t.count] = blocks;
+    hipLaunchKernelGGL(grad_sum_multi_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, t);
+    VG_CHECK_LAUNCH("vg_grad_sum_multi");
   }
   return VG_OK;
 }

@@ -108,6 +108,7 @@ SIGNATURES = {
     "vg_rmsprop_step_multi": (c_int, [c_int, _P, _P, _P, _P, _P, _P, POINTER(RmspropCfg), _P]),
     "vg_adam_step": (c_int, [_P, _P, _P, _P, _P, c_size_t, POINTER(AdamCfg), _P]),
     "vg_adam_step_multi": (c_int, [c_int, _P, _P, _P, _P, _P, _P, POINTER(AdamCfg), _P]),
+    "vg_grad_sum_multi": (c_int, [c_int, _P, _P, _P, _P, _P, _P]),
     "vg_sgd_step": (c_int, [_P, _P, _P, c_size_t, POINTER(SgdCfg), _P]),
     "vg_clamp": (c_int, [_P, c_size_t, c_float, c_float, _P]),
 }
@@ -172,6 +173,12 @@ def freeze_workspace(frozen):
     capture would belong to that graph's memory pool and die with it."""
     global _workspace_frozen
     _workspace_frozen = bool(frozen)
+
+
+def workspace_buffers():
+    """The scratch buffers currently in use (one per device): a captured HIP graph keeps these references so the
+    addresses it recorded stay valid after the shared buffer has been replaced by a larger one."""
+    return list(_workspace.values())
 
 
 def workspace(nbytes, device):

@@ -1,0 +1,172 @@
+"""Engine-owned accumulation of parameter gradients.
+
+In the reference a parameter that is used by several forward passes of one sub-step (the critic of
+WassersteinGANGP.py:88-107 sees the fake batch, the real batch and the interpolates, and the penalty reaches every
+weight twice more through the double backward) gets its gradient summed by torch's `AccumulateGrad` nodes, one
+`add` kernel per contribution, in whatever order the autograd engine happens to run the producers.  Floating-point
+addition of more than two terms depends on that order, and the order is not a property of the program: nodes built
+during a `create_graph` backward take their sequence numbers from the autograd worker thread's private counter.
+
+Here the operators hand every parameter-gradient contribution to a `Ledger` instead of returning it to autograd.
+Each contribution carries a label derived from program order on the calling thread (a ticket drawn when the forward
+operator ran, extended by a fixed child index for operators created inside a backward pass), and when the backward
+pass has finished the ledger adds the contributions of every parameter in label order with one multi-tensor kernel
+(`vg_grad_sum_multi`) and binds the result to `param.grad`.  The sum is therefore a function of the program alone:
+bitwise reproducible between runs, between eager and graph-replayed iterations, and between ranks.
+
+Under data parallelism the ledger writes the (row-weighted) sum straight into the parameter's slot of its all-reduce
+bucket and tells the bucket owner (`sink`) as soon as a parameter is complete, so the collective of a bucket can start
+while the rest of the backward pass is still running.
+"""
+import itertools
+from ctypes import c_float, c_int, c_size_t, c_void_p
+
+import torch
+
+from .. import _hip
+from .._hip import _stream, call
+
+MAX_SOURCES = 8          # contributions one kernel launch adds per tensor (more are chained)
+
+_tickets = itertools.count(1)
+_active = None           # the Ledger that is collecting, else None
+
+
+def ticket():
+    """Label of a forward operator call: program order on the thread that builds the graph."""
+    return (next(_tickets),)
+
+
+def collecting():
+    return _active is not None
+
+
+def route(param, label, grad):
+    """Give `grad` (a contribution to d loss / d param, or None) to the collecting ledger and return None, or return it
+    unchanged when no ledger is collecting for `param` (plain autograd use of the operators: autograd then
+    accumulates)."""
+    led = _active
+    if grad is None or led is None or id(param) not in led.index:
+        return grad
+    led.deposit(param, label, grad)
+    return None
+
+
+def _same_order(t, p):
+    """`t` in the memory order of parameter `p` (the kernels walk raw memory)."""
+    if t.stride() == p.stride() or t.numel() <= 1:
+        return t
+    if p.dim() == 4:
+        from . import ops
+        t = ops.to_nhwc(t) if p.is_contiguous(memory_format=torch.channels_last) else ops.to_nchw(t)
+    elif not t.is_contiguous():
+        from . import ops
+        t = ops._plain_contiguous(t)
+    if t.stride() != p.stride():
+        raise _hip.HipError("gradient strides %s differ from parameter strides %s" % (t.stride(), p.stride()))
+    return t
+
+
+def sum_into(items, scale=1.0):
+    """items: [(param, sources, out)] — write scale * (sources[0] + sources[1] + ...) (added left to right) into `out`
+    (None: in place into sources[0]) for every item with ONE kernel launch per MAX_SOURCES sources; returns the
+    tensors holding the sums."""
+    results = []
+    work = []
+    for p, sources, out in items:
+        sources = [_same_order(s, p) for s in sources]
+        if out is None:
+            if len(sources) == 1 and scale == 1.0:
+                results.append(sources[0])
+                continue
+            out = sources[0]
+        results.append(out)
+        work.append((sources, out))
+    while work:
+        count = len(work)
+        outs = (c_void_p * count)()
+        srcs = (c_void_p * (count * MAX_SOURCES))()
+        nsrc = (c_int * count)()
+        sizes = (c_size_t * count)()
+        scales = (c_float * count)()
+        rest = []
+        for i, (sources, out) in enumerate(work):
+            head, tail = sources[:MAX_SOURCES], sources[MAX_SOURCES:]
+            for t in head + [out]:
+                if not t.is_cuda or t.dtype != torch.float32 or t.numel() != out.numel():
+                    raise _hip.HipError("gradient contribution %s %s does not match its parameter" %
+                                        (t.dtype, tuple(t.shape)))
+            outs[i] = out.data_ptr()
+            for k, t in enumerate(head):
+                srcs[i * MAX_SOURCES + k] = t.data_ptr()
+            nsrc[i] = len(head)
+            sizes[i] = out.numel()
+            # the scale belongs to the finished sum: a chain of launches applies it in its last one
+            scales[i] = 1.0 if tail else scale
+            if tail:
+                rest.append(([out] + tail, out))
+        call("vg_grad_sum_multi", count, outs, srcs, nsrc, sizes, scales, _stream())
+        work = rest
+    return results
+
+
+class Ledger:
+    """Collects the gradient contributions of `params` during one backward pass (context manager)."""
+
+    def __init__(self, params, sink=None, summer=None):
+        self.params = [p for p in params if p.requires_grad]
+        self.index = {id(p): p for p in self.params}
+        self.entries = {}
+        self.sink = sink
+        self.summer = summer if summer is not None else sum_into    # host-logic tests pass a CPU stand-in
+        self.done = set()
+
+    def __enter__(self):
+        global _active
+        if _active is not None:
+            raise _hip.HipError("a gradient ledger is already collecting (nested backward passes of the training step)")
+        for p in self.params:
+            if p.grad is not None:
+                # a gradient left from an earlier backward pass is the first term, as it is for torch's accumulation
+                self.entries[id(p)] = [((), p.grad)]
+        _active = self
+        return self
+
+    def __exit__(self, exc_type, exc, tb):
+        global _active
+        _active = None
+        if exc_type is None:
+            self.close()
+        return False
+
+    def deposit(self, param, label, grad):
+        key = id(param)
+        if key in self.done:
+            raise _hip.HipError("a gradient contribution arrived after its parameter's bucket had been handed to the "
+                                "all-reduce: the model's backward graph changed between two iterations")
+        self.entries.setdefault(key, []).append((label, grad.detach()))
+        if self.sink is not None:
+            self.sink.deposited(self, param, len(self.entries[key]))
+
+    def sources(self, param):
+        rows = sorted(self.entries.get(id(param), ()), key=lambda r: r[0])
+        return [t for _, t in rows]
+
+    def flush(self, params):
+        """Sum what has arrived for `params` now (the data-parallel sink calls this for complete parameters)."""
+        todo = [p for p in params if id(p) not in self.done and id(p) in self.entries]
+        if not todo:
+            return
+        if self.sink is None:
+            outs, scale = [None] * len(todo), 1.0
+        else:
+            outs, scale = [self.sink.slot(p) for p in todo], self.sink.weight
+        sums = self.summer([(p, self.sources(p), o) for p, o in zip(todo, outs)], scale)
+        for p, s in zip(todo, sums):
+            p.grad = s if s.shape == p.shape and s.stride() == p.stride() else s.as_strided(p.shape, p.stride())
+            self.done.add(id(p))
+
+    def close(self):
+        self.flush(self.params)
+        if self.sink is not None:
+            self.sink.closed(self)

@@ -95,6 +95,7 @@ class _StepGraph:
         self.arena_used = 0
         self.losses = None
         self.grads = None
+        self.scratch = None
 
     def carve(self, shape):
         """A static buffer for a host input. It must not come from the graph's own memory pool: the pool hands a block
@@ -140,6 +141,9 @@ class _StepGraph:
         side.wait_stream(torch.cuda.current_stream())
         _capturing = self
         _hip.freeze_workspace(True)
+        # The recorded kernels hold raw addresses of the shared scratch buffers: keep the buffers alive as long as this
+        # graph, whatever a later (larger) eager call replaces them with.
+        self.scratch = _hip.workspace_buffers()
         # No cyclic garbage collection while the stream is capturing: collecting an old model would destroy its graphs
         # and free their memory pools, which HIP forbids during capture.
         gc_was_enabled = gc.isenabled()

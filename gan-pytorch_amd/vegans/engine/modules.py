@@ -116,7 +116,8 @@ def _fused_act(norm, act):
     if type(act) is HipReLU:
         return _hip.ACT_RELU, 0.0
     if type(act) is HipLeakyReLU:
-        return _hip.ACT_LRELU, act.negative_slope
+        # the fused backward reads the slope mask off the sign of the OUTPUT, which needs a non-negative slope
+        return (_hip.ACT_LRELU, act.negative_slope) if act.negative_slope >= 0 else None
     return None
 
 

@@ -9,6 +9,11 @@ them a second time:
     conv_dgrad(gy, w) --backward--> conv_fwd(ggx, w), conv_wgrad(gy, ggx)
     conv_wgrad(gy, x) --backward--> conv_fwd(x, ggw),  conv_dgrad(gy, ggw)
 
+Gradients of parameters are not left to autograd's accumulation: every operator that produces one hands it to the
+gradient ledger (engine/grads.py) under a label derived from program order, and the ledger adds the contributions of a
+parameter in label order.  An operator called by user code draws a fresh ticket as its label; an operator created
+inside a backward pass takes its parent's label extended by a fixed child index.
+
 Memory layout: 4-d activations are NCHW-shaped tensors with channels_last strides (NHWC in memory); 4-d weights
 are kept channels_last as well ([Co][kh][kw][Ci] in memory).  Tensors that arrive in another layout are
 re-laid-out by the layout kernels, never by torch.
@@ -23,6 +28,7 @@ from torch.autograd.function import once_differentiable
 
 from .. import _hip
 from .._hip import ConvGeom, _ptr, _stream, call, workspace
+from . import grads
 
 CL = torch.channels_last
 
@@ -352,24 +358,37 @@ def raw_colsum(x):
 # ----------------------------------------------------------------------------------------------------------------
 # convolution family
 # ----------------------------------------------------------------------------------------------------------------
+def _label(label):
+    return grads.ticket() if label is None else label
+
+
+def _wants_input_grad(ctx, x):
+    """Whether the backward of an operator must produce the gradient of its activation input `x`. A leaf marked
+    `_vg_no_grad_sink` (the gradient penalty's interpolates) is differentiated by `torch.autograd.grad` while the loss is
+    built, but its gradient in the training step's own backward pass would be computed and thrown away."""
+    if not ctx.needs_input_grad[0]:
+        return False
+    return not (grads.collecting() and getattr(x, "_vg_no_grad_sink", False))
+
+
 class ConvFwdFn(Function):
     @staticmethod
-    def forward(ctx, x, w, bias, g):
+    def forward(ctx, x, w, bias, g, label=None):
         # the tensors are saved as given (not their re-laid-out copies) so second-order graphs stay connected
         ctx.g = g
-        ctx.save_for_backward(x, w)
-        ctx.has_bias = bias is not None
+        ctx.label = _label(label)
+        ctx.save_for_backward(x, w, bias)
         return raw_conv_fwd(g, x, w, bias)
 
     @staticmethod
     def backward(ctx, gy):
-        x, w = ctx.saved_tensors
-        g = ctx.g
+        x, w, bias = ctx.saved_tensors
+        g, lab = ctx.g, ctx.label
         params = not inputs_only.active
-        gx = ConvDgradFn.apply(gy, w, None, g) if ctx.needs_input_grad[0] else None
-        gw = ConvWgradFn.apply(gy, x, g, tuple(w.shape)) if (params and ctx.needs_input_grad[1]) else None
-        gb = ColSumFn.apply(gy) if (params and ctx.has_bias and ctx.needs_input_grad[2]) else None
-        return gx, gw, gb, None
+        gx = ConvDgradFn.apply(gy, w, None, g, lab + (0,)) if _wants_input_grad(ctx, x) else None
+        gw = ConvWgradFn.apply(gy, x, g, tuple(w.shape), lab + (1,)) if (params and ctx.needs_input_grad[1]) else None
+        gb = ColSumFn.apply(gy) if (params and bias is not None and ctx.needs_input_grad[2]) else None
+        return gx, grads.route(w, lab, gw), grads.route(bias, lab, gb), None, None
 
 
 class ConvActFn(Function):
@@ -387,57 +406,58 @@ class ConvActFn(Function):
         _launch_conv(0, g, lambda: call("vg_conv2d_fwd_act", ctypes.byref(g.c), _ptr(xm), _ptr(wm), _ptr(bias), _ptr(y),
                                         act, c_float(slope), _stream()))
         ctx.g, ctx.act, ctx.slope = g, act, slope
-        ctx.has_bias = bias is not None
-        ctx.save_for_backward(x, w, y)
+        ctx.label = grads.ticket()
+        ctx.save_for_backward(x, w, bias, y)
         return y
 
     @staticmethod
     def backward(ctx, gy):
-        x, w, y = ctx.saved_tensors
-        g = ctx.g
+        x, w, bias, y = ctx.saved_tensors
+        g, lab = ctx.g, ctx.label
         gpre = ActBwdFn.apply(gy, y, ctx.act, ctx.slope)
         params = not inputs_only.active
-        gx = ConvDgradFn.apply(gpre, w, None, g) if ctx.needs_input_grad[0] else None
-        gw = ConvWgradFn.apply(gpre, x, g, tuple(w.shape)) if (params and ctx.needs_input_grad[1]) else None
-        gb = ColSumFn.apply(gpre) if (params and ctx.has_bias and ctx.needs_input_grad[2]) else None
-        return gx, gw, gb, None, None, None
+        gx = ConvDgradFn.apply(gpre, w, None, g, lab + (0,)) if _wants_input_grad(ctx, x) else None
+        gw = ConvWgradFn.apply(gpre, x, g, tuple(w.shape), lab + (1,)) if (params and ctx.needs_input_grad[1]) else None
+        gb = ColSumFn.apply(gpre) if (params and bias is not None and ctx.needs_input_grad[2]) else None
+        return gx, grads.route(w, lab, gw), grads.route(bias, lab, gb), None, None, None
 
 
 class ConvDgradFn(Function):
     """gx = conv_transpose(gy, w) (+bias over the Ci channels): also the forward of ConvTranspose2d."""
 
     @staticmethod
-    def forward(ctx, gy, w, bias, g):
+    def forward(ctx, gy, w, bias, g, label=None):
         ctx.g = g
-        ctx.save_for_backward(gy, w)
-        ctx.has_bias = bias is not None
+        ctx.label = _label(label)
+        ctx.save_for_backward(gy, w, bias)
         return raw_conv_dgrad(g, gy, w, bias)
 
     @staticmethod
     def backward(ctx, ggx):
-        gy, w = ctx.saved_tensors
-        g = ctx.g
+        gy, w, bias = ctx.saved_tensors
+        g, lab = ctx.g, ctx.label
         params = not inputs_only.active
-        d_gy = ConvFwdFn.apply(ggx, w, None, g) if ctx.needs_input_grad[0] else None
-        d_w = ConvWgradFn.apply(gy, ggx, g, tuple(w.shape)) if (params and ctx.needs_input_grad[1]) else None
-        d_b = ColSumFn.apply(ggx) if (params and ctx.has_bias and ctx.needs_input_grad[2]) else None
-        return d_gy, d_w, d_b, None
+        d_gy = ConvFwdFn.apply(ggx, w, None, g, lab + (0,)) if _wants_input_grad(ctx, gy) else None
+        d_w = ConvWgradFn.apply(gy, ggx, g, tuple(w.shape), lab + (1,)) if (params and ctx.needs_input_grad[1]) else None
+        d_b = ColSumFn.apply(ggx) if (params and bias is not None and ctx.needs_input_grad[2]) else None
+        return d_gy, grads.route(w, lab, d_w), grads.route(bias, lab, d_b), None, None
 
 
 class ConvWgradFn(Function):
     @staticmethod
-    def forward(ctx, gy, x, g, w_shape):
+    def forward(ctx, gy, x, g, w_shape, label=None):
         ctx.g = g
+        ctx.label = _label(label)
         ctx.save_for_backward(gy, x)
         return raw_conv_wgrad(g, gy, x, w_shape)
 
     @staticmethod
     def backward(ctx, ggw):
         gy, x = ctx.saved_tensors
-        g = ctx.g
-        d_gy = ConvFwdFn.apply(x, ggw, None, g) if ctx.needs_input_grad[0] else None
-        d_x = ConvDgradFn.apply(gy, ggw, None, g) if ctx.needs_input_grad[1] else None
-        return d_gy, d_x, None, None
+        g, lab = ctx.g, ctx.label
+        d_gy = ConvFwdFn.apply(x, ggw, None, g, lab + (0,)) if ctx.needs_input_grad[0] else None
+        d_x = ConvDgradFn.apply(gy, ggw, None, g, lab + (1,)) if ctx.needs_input_grad[1] else None
+        return d_gy, d_x, None, None, None
 
 
 class ColSumFn(Function):
@@ -537,19 +557,17 @@ class BatchNormTrainFn(Function):
         call("vg_bn_apply", _ptr(x), _ptr(mean), _ptr(invstd), _ptr(gamma), _ptr(beta), _ptr(y), m, c,
              act, c_float(slope), _stream())
         ctx.act, ctx.slope = act, slope
-        if act == _hip.ACT_NONE:
-            ctx.save_for_backward(x_in, gamma, mean, invstd)
-        else:
-            ctx.save_for_backward(x_in, gamma, mean, invstd, y)
-        ctx.has_affine = (gamma is not None, beta is not None)
+        ctx.label = grads.ticket()
+        ctx.save_for_backward(x_in, gamma, beta, mean, invstd, y if act != _hip.ACT_NONE else None)
         return y
 
     @staticmethod
     def backward(ctx, gy):
-        x, gamma, mean, invstd = ctx.saved_tensors[:4]
-        y = ctx.saved_tensors[4] if ctx.act != _hip.ACT_NONE else None
-        gx, ggamma, gbeta = BatchNormBwdFn.apply(gy, x, gamma, mean, invstd, y, ctx.act, ctx.slope)
-        return (gx, ggamma if ctx.has_affine[0] else None, gbeta if ctx.has_affine[1] else None,
+        x, gamma, beta, mean, invstd, y = ctx.saved_tensors
+        lab = ctx.label
+        gx, ggamma, gbeta = BatchNormBwdFn.apply(gy, x, gamma, mean, invstd, y, ctx.act, ctx.slope, lab + (0,))
+        return (gx, grads.route(gamma, lab, ggamma) if gamma is not None else None,
+                grads.route(beta, lab, gbeta) if beta is not None else None,
                 None, None, None, None, None, None, None)
 
 
@@ -559,9 +577,10 @@ class BatchNormBwdFn(Function):
     fused activation (or None): it only supplies the piecewise-constant slope mask, so it carries no gradient."""
 
     @staticmethod
-    def forward(ctx, gy, x, gamma, mean, invstd, act_out, act, slope):
+    def forward(ctx, gy, x, gamma, mean, invstd, act_out, act, slope, label=None):
         ctx.save_for_backward(gy, x, gamma, mean, invstd, act_out)
         ctx.act, ctx.slope = act, slope
+        ctx.label = _label(label)
         gy, x = to_nhwc(gy), to_nhwc(x)
         m, c = _rows_cols(x)
         mask = _act_args(act_out, act, slope)
@@ -597,7 +616,9 @@ class BatchNormBwdFn(Function):
         d_gamma = torch.empty(c, dtype=torch.float32, device=x.device) if gamma is not None else None
         call("vg_bn_dbwd_apply", _ptr(gy), _ptr(x), _ptr(u), _ptr(v), _ptr(w), _ptr(mean), _ptr(invstd), _ptr(gamma),
              _ptr(sums5), _ptr(d_gy), _ptr(d_x), _ptr(d_gamma), m, c, *mask, _stream())
-        return d_gy, d_x, d_gamma, None, None, None, None, None
+        if gamma is not None:
+            d_gamma = grads.route(gamma, ctx.label, d_gamma)
+        return d_gy, d_x, d_gamma, None, None, None, None, None, None
 
 
 class BatchNormEvalFn(Function):
@@ -611,14 +632,15 @@ class BatchNormEvalFn(Function):
         call("vg_bn_apply", _ptr(x), _ptr(running_mean), _ptr(invstd), _ptr(gamma), _ptr(beta), _ptr(y), m, c,
              act, c_float(slope), _stream())
         ctx.act, ctx.slope = act, slope
-        ctx.save_for_backward(x, gamma, running_mean, invstd, y if act != _hip.ACT_NONE else None)
+        ctx.label = grads.ticket()
+        ctx.save_for_backward(x, gamma, beta, running_mean, invstd, y if act != _hip.ACT_NONE else None)
         ctx.has_affine = (gamma is not None, beta is not None)
         return y
 
     @staticmethod
     @once_differentiable
     def backward(ctx, gy):
-        x, gamma, mean, invstd, y = ctx.saved_tensors
+        x, gamma, beta, mean, invstd, y = ctx.saved_tensors
         gy = to_nhwc(gy)
         m, c = _rows_cols(x)
         if y is not None:  # undo the fused activation first: g = gy * act'(y)
@@ -633,8 +655,8 @@ class BatchNormEvalFn(Function):
             ws, nbytes = _bn_ws(m, c, x.device)
             call("vg_bn_bwd_reduce", _ptr(gy), _ptr(x), _ptr(mean), _ptr(invstd), m, c, _ptr(sums),
                  ctypes.c_void_p(ws.data_ptr()), c_size_t(nbytes), None, _hip.ACT_NONE, c_float(0.0), _stream())
-            ggamma = sums[1] if ctx.has_affine[0] else None
-            gbeta = sums[0] if ctx.has_affine[1] else None
+            ggamma = grads.route(gamma, ctx.label, sums[1]) if ctx.has_affine[0] else None
+            gbeta = grads.route(beta, ctx.label, sums[0]) if ctx.has_affine[1] else None
         return gx, ggamma, gbeta, None, None, None, None, None
 
 
@@ -788,10 +810,11 @@ def _reduce_ws(n, device):
 
 
 def _flat_dense(t):
+    """`t` as one gap-free block the loss kernels can walk as flat memory (a channel / column slice is compacted)."""
     _require_gpu(t)
-    if not (t.is_contiguous() or t.is_contiguous(memory_format=CL)):
-        _plain_contiguous(t)
-    return t
+    if t.is_contiguous() or t.is_contiguous(memory_format=CL):
+        return t
+    return _plain_contiguous(t)
 
 
 class MeanLossFn(Function):
@@ -947,16 +970,52 @@ def gp_interpolate(alpha, real, fake):
     _require_gpu(alpha)
     out = torch.empty_like(real)
     call("vg_gp_interp", _ptr(alpha), _ptr(real), _ptr(fake), _ptr(out), b, c_size_t(real.numel() // b), _stream())
-    return out.requires_grad_(True)
+    return _penalty_leaf(out)
+
+
+def _penalty_leaf(t):
+    # differentiated by torch.autograd.grad while the loss is built; the training step's own backward pass has no use
+    # for d loss / d interpolates (see _wants_input_grad)
+    t.requires_grad_(True)
+    t._vg_no_grad_sink = True
+    return t
+
+
+def gp_interpolate_pairs(alpha, real, fake):
+    """The reference's interpolation for VECTOR data (2-d `real` [B, D]): its alpha has shape [B, 1, 1, 1]
+    (WassersteinGANGP.py:68), which broadcasts against [B, D] to [B, 1, B, D]: every alpha is paired with every sample,
+    out[i][j] = alpha[i]*real[j] + (1-alpha[i])*fake[j]. Returned as the [B*B, D] leaf the critic is applied to; the
+    penalty then takes one norm per alpha over all B*D gradient elements of its row block (`gradient_penalty(rows=B)`)."""
+    real = _dense_like(real.detach())
+    fake = _match_layout(_dense_like(fake.detach()), real)
+    if real.dim() != 2 or real.shape != fake.shape:
+        raise _hip.HipError("pairwise interpolation expects two [B, D] tensors, got %s and %s" %
+                            (tuple(real.shape), tuple(fake.shape)))
+    b, d = real.shape
+    alpha = alpha.reshape(-1)
+    if alpha.numel() != b or not alpha.is_contiguous():
+        raise _hip.HipError("alpha must hold one value per sample")
+    _require_gpu(alpha)
+    tiled_real = torch.empty((b, b * d), dtype=torch.float32, device=real.device)
+    tiled_fake = torch.empty((b, b * d), dtype=torch.float32, device=real.device)
+    call("vg_bcast_rows", _ptr(real), _ptr(tiled_real), b, b * d, _stream())
+    call("vg_bcast_rows", _ptr(fake), _ptr(tiled_fake), b, b * d, _stream())
+    out = torch.empty((b * b, d), dtype=torch.float32, device=real.device)
+    call("vg_gp_interp", _ptr(alpha), _ptr(tiled_real), _ptr(tiled_fake), _ptr(out), b, c_size_t(b * d), _stream())
+    return _penalty_leaf(out)
 
 
 class GradPenaltyFn(Function):
-    """mean_b (||g_b||_2 - 1)^2 over per-sample gradients g (any layout: the norm runs over all elements of a sample)."""
+    """mean_b (||g_b||_2 - 1)^2 over per-sample gradients g (any layout: the norm runs over all elements of a sample).
+    `rows` overrides the number of samples b (the memory is then read as b equal consecutive blocks)."""
 
     @staticmethod
-    def forward(ctx, g):
+    def forward(ctx, g, rows=None):
         g = _dense_like(g)
-        b = g.shape[0]
+        b = g.shape[0] if rows is None else rows
+        if g.numel() % b:
+            raise _hip.HipError("gradient of %d elements does not divide into %d samples" % (g.numel(), b))
+        ctx.rows = b
         d = g.numel() // b
         norms = torch.empty(b, dtype=torch.float32, device=g.device)
         call("vg_gp_rownorm", _ptr(g), _ptr(norms), b, c_size_t(d), _stream())
@@ -969,14 +1028,30 @@ class GradPenaltyFn(Function):
     @once_differentiable
     def backward(ctx, gout):
         g, norms = ctx.saved_tensors
-        b = g.shape[0]
+        b = ctx.rows
         dg = torch.empty_like(g)
         call("vg_gp_penalty_bwd", _ptr(gout), _ptr(g), _ptr(norms), _ptr(dg), b, c_size_t(g.numel() // b), _stream())
-        return dg
+        return dg, None
 
 
-def gradient_penalty(grads):
-    return GradPenaltyFn.apply(grads)
+def gradient_penalty(gradients, rows=None):
+    return GradPenaltyFn.apply(gradients, rows)
+
+
+_unit = {}
+
+
+def unit_scalar(device):
+    """A 0-d device tensor holding 1.0: the seed gradient of `loss.backward` (created once per device; handed to
+    backward explicitly so that no stock fill kernel runs per backward pass)."""
+    device = torch.device(device)
+    key = device.index if device.index is not None else torch.cuda.current_device()
+    t = _unit.get(key)
+    if t is None:
+        t = torch.empty((), dtype=torch.float32, device=device)
+        call("vg_fill", _ptr(t), c_float(1.0), c_size_t(1), _stream())
+        _unit[key] = t
+    return t
 
 
 def fill_(t, value):
@@ -1075,5 +1150,9 @@ def flatten(x):
     n, c, h, w = x.shape
     if c == 1 or h * w == 1:
         # memory order is the same in both layouts: a pure view
-        return x.reshape(n, c * h * w)
-    return FlattenFn.apply(x)
+        out = x.reshape(n, c * h * w)
+    else:
+        out = FlattenFn.apply(x)
+    if getattr(x, "_vg_no_grad_sink", False):
+        out._vg_no_grad_sink = True
+    return out

@@ -62,6 +62,10 @@ def fused_step(optimizer, grad_scale=1.0, clamp=None):
     else:
         raise NotImplementedError(
             "optimizer %s has no fused MI355X kernel (supported: RMSprop, Adam, AdamW, SGD)" % kind.__name__)
+    if clamp is not None:
+        # the reference clamps EVERY critic parameter after the step (WassersteinGAN.py:78-79); the fused kernels only
+        # visit parameters that have a gradient
+        clamp_([p for group in optimizer.param_groups for p in group["params"] if p.grad is None], lo, hi)
 
 
 def _pointer_array(tensors):

@@ -5,19 +5,17 @@ every forward it re-broadcasts the weights, scatters contiguous row chunks of th
 gradients to device 0.  Here each rank keeps its own resident replica; per batch it takes the same contiguous
 row chunk DataParallel's scatter would give it (`torch.chunk` sizes), computes losses as means over its rows,
 and after backward the weight gradients of the network being trained are all-reduced (sum) in a few buckets.
-Each bucket's all-reduce is issued from a post-accumulate hook as soon as its last gradient exists, so it
-overlaps with the rest of backward; the rank's weight rows/global_rows is applied while the gradient is copied
-into its bucket, and the fused optimizer kernel then applies the identical update on every rank.  BatchNorm statistics stay per rank, as they
+The gradient ledger (engine/grads.py) adds each parameter's contributions in a fixed order straight into its bucket slot,
+with the rank's weight rows/global_rows applied; a bucket's all-reduce is issued as soon as its last parameter is
+complete, so it overlaps with the rest of backward, and the fused optimizer kernel then applies the identical update on
+every rank.  BatchNorm statistics stay per rank, as they
 are per replica under DataParallel.
 """
 import os
-from ctypes import c_float, c_size_t
-
 import torch
 import torch.distributed as dist
 
-from . import graph
-from .._hip import _ptr, _stream, call
+from . import grads, graph
 
 BUCKETS_PER_NET = 3
 
@@ -81,17 +79,21 @@ def context(model):
     return model._dp
 
 
-def _scaled_copy(src, weight, dst):
-    call("vg_scale", _ptr(src), c_float(weight), _ptr(dst), c_size_t(src.numel()), _stream())
-
-
 class GradReducer:
-    """Bucketed gradient all-reduce for one network. `copy(src, weight, dst)` writes weight*src into the bucket
-    (the HIP scale kernel; host-logic tests pass their own)."""
+    """Bucketed gradient all-reduce for one network, fed by the gradient ledger (engine/grads.py).
 
-    def __init__(self, params, n_buckets=BUCKETS_PER_NET, copy=_scaled_copy):
-        self._copy = copy
+    `open(weight)` starts a backward pass and returns the ledger that collects the network's parameter gradients. The
+    ledger writes weight * (sum of a parameter's contributions, in label order) into the parameter's slot of its bucket;
+    eagerly it does so as soon as the parameter has received as many contributions as in the previous backward pass, and
+    a bucket whose parameters are all complete is all-reduced at once, while the rest of the backward pass is still
+    running. `finish()` waits for the collectives (or, while an iteration is being captured into HIP graphs, cuts the
+    capture and schedules them between two graph launches). `summer` replaces the HIP summation kernel in host-logic
+    tests."""
+
+    def __init__(self, params, n_buckets=BUCKETS_PER_NET, summer=None):
+        self._summer = summer
         params = [p for p in params if p.requires_grad]
+        self.params = params
         # gradients become available roughly in reverse parameter order during backward
         order = list(reversed(params))
         total = sum(p.numel() for p in order)
@@ -119,57 +121,82 @@ class GradReducer:
         for bi, b in enumerate(self.buckets):
             off = 0
             for p in b:
-                self.where[p] = (bi, off)
+                self.where[id(p)] = (bi, off)
                 off += p.numel()
         self.pending = [0] * len(self.buckets)
+        self.touched = [False] * len(self.buckets)
+        self.launched = [False] * len(self.buckets)
         self.works = []
-        self.local_weight = 1.0
+        self.next = 0           # first bucket not yet handed to the collective
+        self.weight = 1.0
+        self.counts = None      # id(param) -> contributions it received in the previous backward pass
         self.armed = False
-        for p in params:
-            p.register_post_accumulate_grad_hook(self._on_grad)
 
-    def arm(self, local_weight):
-        """Start collecting the next backward; `local_weight` scales this rank's gradients before the sum."""
+    def open(self, local_weight):
+        """Start collecting the next backward pass; `local_weight` scales this rank's gradients before the sum."""
         self.pending = [len(b) for b in self.buckets]
+        self.touched = [False] * len(self.buckets)
+        self.launched = [False] * len(self.buckets)
         self.works = []
-        self.local_weight = float(local_weight)
+        self.next = 0
+        self.weight = float(local_weight)
         self.armed = True
+        return grads.Ledger(self.params, sink=self, summer=self._summer)
 
-    def _on_grad(self, p):
-        if not self.armed or p.grad is None:
+    # -- ledger sink protocol ------------------------------------------------------------------------------------
+    def slot(self, p):
+        bi, off = self.where[id(p)]
+        return self.flat[bi][off:off + p.numel()]
+
+    def deposited(self, ledger, p, n_so_far):
+        if graph.capturing() or self.counts is None or self.counts.get(id(p)) != n_so_far:
             return
-        bi, off = self.where[p]
-        flat = self.flat[bi]
-        view = flat[off:off + p.numel()]
-        g = p.grad
-        self._copy(g, self.local_weight, view)
-        # the optimizer reads the reduced values straight from the bucket, in the parameter's memory order
-        p.grad = view.as_strided(p.shape, g.stride())
+        ledger.flush([p])
+        self._completed(p)
+
+    def _completed(self, p):
+        bi, _ = self.where[id(p)]
+        self.touched[bi] = True
         self.pending[bi] -= 1
-        if self.pending[bi] == 0 and not graph.capturing():
-            self.works.append(_all_reduce_async(flat))
+        # Buckets are handed to the collective strictly in bucket order: the order in which parameters complete depends
+        # on how autograd schedules the backward pass, which may differ between ranks, and ranks that issue their
+        # collectives in different orders pair up the wrong buffers.
+        while self.next < len(self.buckets) and self.pending[self.next] == 0:
+            self.launched[self.next] = True
+            self.works.append(_all_reduce_async(self.flat[self.next]))
+            self.next += 1
+
+    def closed(self, ledger):
+        """The backward pass is over and the ledger has written every parameter that received a gradient."""
+        seen = {key: len(rows) for key, rows in ledger.entries.items()}
+        for p in self.params:
+            if id(p) in seen:
+                self.touched[self.where[id(p)][0]] = True
+        self.counts = seen
+        if not graph.capturing():
+            # buckets that got gradients but were not launched from `deposited` (first pass, changed graph, parameters
+            # without a gradient this time)
+            for bi in range(len(self.buckets)):
+                if self.touched[bi] and not self.launched[bi]:
+                    self.launched[bi] = True
+                    self.works.append(_all_reduce_async(self.flat[bi]))
 
     def finish(self):
-        """Flush buckets whose parameters got no gradient this time and wait for every all-reduce."""
+        """Wait for every all-reduce of the pass (eager), or schedule them between two graph launches (capturing)."""
         if not self.armed:
             return
+        self.armed = False
         if graph.capturing():
-            # the iteration is being recorded into HIP graphs: nothing was launched from the hooks; cut the recording
-            # here and let every replay all-reduce the buckets that received gradients, between two graph launches
-            flats = [self.flat[bi] for bi, left in enumerate(self.pending) if left < len(self.buckets[bi])]
+            flats = [self.flat[bi] for bi in range(len(self.buckets)) if self.touched[bi]]
             if len(flats) == len(self.flat) and len(flats) > 1:
                 flats = [self.whole]          # one collective instead of one per bucket (padding between them is zero)
-            self.armed = False
-            graph.cut(lambda: _all_reduce_now(flats))
+            if flats:
+                graph.cut(lambda: _all_reduce_now(flats))
             return
-        for bi, left in enumerate(self.pending):
-            if 0 < left < len(self.buckets[bi]):
-                self.works.append(_all_reduce_async(self.flat[bi]))
         for w in self.works:
             if w is not None:
                 w.wait()
         self.works = []
-        self.armed = False
 
 
 def _gloo():
@@ -213,16 +240,21 @@ def _all_reduce_now(flats):
         torch.cuda.synchronize()
 
 
-def arm(model, who):
-    """Called before backward of a sub-step: prepare the reducer of the network being trained."""
+def open_ledger(model, who):
+    """The gradient ledger of one backward pass of network `who` (None: every network): collects the parameter
+    gradients the operators produce and adds them in a fixed order; under data parallelism it writes them into the
+    all-reduce buckets of the network's reducer."""
+    names = [who] if who is not None else list(model.neural_nets)
     ctx = getattr(model, "_dp", None)
     if ctx is None or ctx.world == 1:
-        return
-    names = [who] if who is not None else list(model.neural_nets)
-    for name in names:
-        red = getattr(model.neural_nets[name], "_vg_reducer", None)
-        if red is not None:
-            red.arm(ctx.local_rows / float(ctx.global_rows))
+        return grads.Ledger([p for name in names for p in model.neural_nets[name].parameters()])
+    if len(names) != 1:
+        raise NotImplementedError("under data parallelism the networks are stepped one at a time (who=None is "
+                                  "not supported with ngpu > 1)")
+    red = getattr(model.neural_nets[names[0]], "_vg_reducer", None)
+    if red is None:
+        raise RuntimeError("network %s has no gradient reducer: parallel.context(model) was not called" % names[0])
+    return red.open(ctx.local_rows / float(ctx.global_rows))
 
 
 def reduce_gradients(model, name):

@@ -68,6 +68,7 @@ class AbstractGenerativeModel(ABC):
         self.to(self.device)
 
         self.images_produced = len(self.adversariat.input_size) > 1
+        ops.unit_scalar(self.device)        # created outside any graph capture
         self.fixed_noise = self.sample(n=fixed_noise_size)
         self._check_attributes()
         self.hyperparameters = {
@@ -388,13 +389,18 @@ class AbstractGenerativeModel(ABC):
                 optimizer.zero_grad()
 
     def _backward(self, who=None):
+        """`loss.backward(retain_graph=True)` of AbstractGenerativeModel.py:367-372. Parameter gradients are collected
+        by the engine's gradient ledger and added in a fixed order (engine/grads.py) instead of by autograd's
+        accumulation; the seed gradient is a resident device scalar."""
         assert len(self._losses) != 0, "'self._losses' empty when performing '_backward'."
-        parallel.arm(self, who)
-        if who is not None:
-            self._losses[who].backward(retain_graph=True)
-        else:
-            for loss in self._losses.values():
-                loss.backward(retain_graph=True)
+        seed = ops.unit_scalar(self.device)
+        with parallel.open_ledger(self, who):
+            if who is not None:
+                self._losses[who].backward(gradient=seed, retain_graph=True)
+            else:
+                for loss in self._losses.values():
+                    if loss.requires_grad:
+                        loss.backward(gradient=seed, retain_graph=True)
 
     def _step(self, who=None, clamp=None):
         names = [who] if who is not None else list(self.optimizers)

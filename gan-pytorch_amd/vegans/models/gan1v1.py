@@ -140,15 +140,22 @@ class _PenaltyMixin:
         return graph.host_input((n_local, 1, 1, 1), draw, self.device)
 
     def _gradient_penalty(self, real_images, fake_images):
-        alpha = self._draw_alpha(real_images.size(0))
-        interpolates = ops.gp_interpolate(alpha, real_images, fake_images)
+        rows = real_images.size(0)
+        alpha = self._draw_alpha(rows)
+        if real_images.dim() == 2:
+            # vector data: the reference's [B,1,1,1] alpha broadcasts against [B,D] to all B x B (alpha, sample)
+            # pairs, and its norm runs over the B*D gradient elements that belong to one alpha
+            # (WassersteinGANGP.py:68-69,80-81)
+            interpolates = ops.gp_interpolate_pairs(alpha, real_images, fake_images)
+        else:
+            interpolates = ops.gp_interpolate(alpha, real_images, fake_images)
         d_interpolates = self.adversariat(interpolates)
         ones = torch.empty_like(d_interpolates)
         ops.fill_(ones, 1.0)
         with ops.inputs_only():
             gradients = torch.autograd.grad(outputs=d_interpolates, inputs=interpolates, grad_outputs=ones,
                                             create_graph=True, retain_graph=True, only_inputs=True)[0]
-        return ops.gradient_penalty(gradients)
+        return ops.gradient_penalty(gradients, rows=rows)
 
 
 # -- unconditional algorithms -------------------------------------------------------------------------------------

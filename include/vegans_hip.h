@@ -281,6 +281,14 @@ int vg_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg
 int vg_adam_step_multi(int count, float* const* params, const float* const* grads, float* const* exp_avgs,
                        float* const* exp_avg_sqs, float* const* max_exp_avg_sqs, const size_t* n,
                        const vg_adam_cfg* cfg, void* stream);
+/* Sum of the gradient contributions a parameter receives within one backward pass, replacing the `AccumulateGrad`
+ * additions torch performs for `loss.backward(retain_graph=True)` (AbstractGenerativeModel.py:367-372) when a network is
+ * applied to several batches in one sub-step (WassersteinGANGP.py:88-107: fake, real, interpolates, and the penalty's
+ * double backward). For every tensor t: outs[t] = scales[t] * (((src 0 + src 1) + src 2) + ...), the nsrc[t] (1..8)
+ * sources added in the order given, so the caller fixes the floating-point result by fixing the order. `srcs` holds
+ * count*8 device pointers (tensor t's sources at srcs[8*t ..]); outs[t] may alias one of its sources; host arrays. */
+int vg_grad_sum_multi(int count, float* const* outs, const float* const* srcs, const int* nsrc, const size_t* n,
+                      const float* scales, void* stream);
 typedef struct vg_sgd_cfg {
   float lr, momentum, dampening, weight_decay;
   int32_t nesterov;

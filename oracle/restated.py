@@ -276,32 +276,77 @@ class OracleGAN:
                 p.data.clamp_(-self.clip_val, self.clip_val)
         return totals
 
-    def fit(self, X_train, y_train=None, epochs=1, batch_size=32, steps=None, latents=None, alphas=None, shards=1):
-        """The hot loop of AbstractGenerativeModel.py:312-327 / AbstractConditionalGenerativeModel.py:125-141
-        (logging off). `latents` / `alphas` are optional iterators of injected Z batches / alpha arrays; when
-        absent Z comes from torch.randn and alpha from numpy's global generator in the reference's order.
+    def fit(self, X_train, y_train=None, epochs=1, batch_size=32, steps=None, latents=None, alphas=None, shards=1,
+            X_test=None, y_test=None, print_every=None, save_losses_every=None):
+        """The hot loop of AbstractGenerativeModel.py:312-327 / AbstractConditionalGenerativeModel.py:125-141.
+        `latents` / `alphas` are optional iterators of injected Z batches / alpha arrays; when absent Z comes from
+        torch.randn and alpha from numpy's global generator in the reference's order.
         `shards` > 1 runs every sub-step the way nn.DataParallel would over that many devices (sub_step_sharded).
+        `print_every` / `save_losses_every` (ints, in batches) add the reference's logging passes
+        (AbstractGenerativeModel.py:329-351, AbstractConditionalGenerativeModel.py:143-171): each is a full
+        `calculate_losses(who=None)` in TRAIN mode, so it updates BatchNorm running statistics, draws one alpha for the
+        gradient penalty and, for the test pass, one latent batch; the values land in `self.logged_losses`.
         Returns the list of per-sub-step loss dicts."""
         plan = {name: 1 for name in self.nets}
         plan.update(steps or {})
         latents = iter(latents) if latents is not None else None
         alphas = iter(alphas) if alphas is not None else None
+
+        def draw_z(n):
+            return next(latents) if latents is not None else self.sample(n)
+
+        def draw_alpha():
+            return next(alphas) if (alphas is not None and self.algo == "wgangp") else None
+
+        test_x = test_y = None
+        if X_test is not None:
+            # `next(iter(test_dataloader))` (AbstractGenerativeModel.py:306; twice in
+            # AbstractConditionalGenerativeModel.py:115-116): every DataLoader iterator draws a base seed from torch's
+            # global generator before its first batch
+            for _ in range(2 if self.conditional else 1):
+                test_x, test_y = next(batches(X_test, y_test, batch_size))
+        self.logged_losses = None
         history = []
         self._set_mode(True)
+        step = 0
         for _ in range(epochs):
             for X, y in batches(X_train, y_train, batch_size):
-                Z = next(latents) if latents is not None else self.sample(len(X))
+                step += 1
+                Z = draw_z(len(X))
                 for name in self.nets:
                     for _ in range(plan[name]):
-                        alpha = None
-                        if self.algo == "wgangp" and name == "Adversariat" and alphas is not None:
-                            alpha = next(alphas)
+                        alpha = draw_alpha() if name == "Adversariat" else None
                         if shards > 1:
                             history.append((name, self.sub_step_sharded(name, X, Z, y, alpha, shards)))
                         else:
                             history.append((name, self.sub_step(name, X, Z, y, alpha)))
+                if print_every is not None and step % print_every == 0:
+                    self.all_losses(X, Z, y, draw_alpha())                       # :329-335 (values printed only)
+                if save_losses_every is not None and step % save_losses_every == 0:
+                    # the conditional classes log the TRAIN images against the TEST labels
+                    # (AbstractConditionalGenerativeModel.py:162)
+                    self._log("Train", self.all_losses(X, Z, test_y if self.conditional else None, draw_alpha()),
+                              X_test is not None)
+                    if test_x is not None:
+                        self._log("Test", self.all_losses(test_x, draw_z(len(test_x)), test_y, draw_alpha()), True)
         self._set_mode(False)
         return history
+
+    def all_losses(self, X, Z, y=None, alpha=None):
+        """`calculate_losses(who=None)`: every network's loss on one batch, generator first
+        (AbstractGAN1v1.py:57-64, LRGAN.py:83-93)."""
+        out = {}
+        for who in self.nets:
+            out.update(self.losses(who, X, Z, y, alpha if who == "Adversariat" else None))
+        return {k: float(v.detach()) for k, v in out.items()}
+
+    def _log(self, mode, values, with_test):
+        """AbstractGenerativeModel.py:438-453. The "Test" key exists whenever logging happens: `nr_test` is 0, not None,
+        without a test set (:158, :445)."""
+        if self.logged_losses is None:
+            self.logged_losses = {"Train": {k: [] for k in values}, "Test": {k: [] for k in values}}
+        for k, v in values.items():
+            self.logged_losses[mode][k].append(v)
 
     def fixed_samples(self, y=None):
         """AbstractGenerativeModel.py:474-496 — eval-mode samples from the fixed noise."""

@@ -48,6 +48,7 @@ def run_reference(name, case):
     if case["algo"] == "lrgan":
         init["Encoder"] = _state(E)
     X, y = _data(case)
+    Xt, yt = _data(case, test=True) if "n_test" in case else (None, None)
     torch.manual_seed(7)
     np.random.seed(7)
     extra = dict(device="cpu", folder=None)
@@ -84,11 +85,14 @@ def run_reference(name, case):
     recording["on"] = True
     fit_kw = dict(epochs=1, batch_size=case["batch"], steps=copy.deepcopy(case.get("steps")), print_every=None,
                   save_losses_every=None, enable_tensorboard=False)
+    fit_kw.update(case.get("fit", {}))
     try:
         if y is None:
             model.fit(X, **fit_kw)
-        else:
+        elif Xt is None:
             model.fit(X, y, **fit_kw)
+        else:
+            model.fit(X, y, X_test=Xt, y_test=yt, **fit_kw)
     finally:
         np.random.random = orig_random
         recording["on"] = False
@@ -100,14 +104,16 @@ def run_reference(name, case):
         samples = model.generate(z=model.fixed_noise)
     else:
         samples = model.generate(y=model.fixed_labels, z=model.fixed_noise)
-    return dict(init=init, X=X, y=y, Z=rec["Z"], alpha=rec["alpha"], losses=rec["losses"], final=final,
-                samples=np.asarray(samples), fixed_noise=model.fixed_noise.detach().numpy().copy())
+    return dict(init=init, X=X, y=y, Xt=Xt, yt=yt, Z=rec["Z"], alpha=rec["alpha"], losses=rec["losses"], final=final,
+                samples=np.asarray(samples), fixed_noise=model.fixed_noise.detach().numpy().copy(),
+                logged=copy.deepcopy(getattr(model, "logged_losses", None)))
 
 
 def run_oracle(case, inject=None):
     """Restatement run; with inject=None it draws Z/alpha itself from the same seeds as the reference run."""
     G, D, E = _nets(case)
     X, y = _data(case)
+    Xt, yt = _data(case, test=True) if "n_test" in case else (None, None)
     torch.manual_seed(7)
     np.random.seed(7)
     o = OracleGAN(case["algo"], G, D, case["x_dim"], case["z_dim"], y_dim=case.get("y_dim"), encoder=E,
@@ -115,10 +121,13 @@ def run_oracle(case, inject=None):
     kw = {}
     if inject is not None:
         kw = dict(latents=[torch.from_numpy(z) for z in inject["Z"]], alphas=list(inject["alpha"]))
-    hist = o.fit(X, y, epochs=1, batch_size=case["batch"], steps=copy.deepcopy(case.get("steps")), **kw)
+    kw.update(case.get("fit", {}))
+    hist = o.fit(X, y, epochs=1, batch_size=case["batch"], steps=copy.deepcopy(case.get("steps")), X_test=Xt, y_test=yt,
+                 **kw)
     final = {k: _state(v) for k, v in o.nets.items()}
     ylab = torch.from_numpy(y[:FIXED]) if y is not None else None
-    return dict(losses=hist, final=final, samples=o.fixed_samples(ylab), fixed_noise=o.fixed_noise.detach().numpy())
+    return dict(losses=hist, final=final, samples=o.fixed_samples(ylab), fixed_noise=o.fixed_noise.detach().numpy(),
+                logged=o.logged_losses)
 
 
 def _assert_identical(ref, orc, name):
@@ -133,12 +142,25 @@ def _assert_identical(ref, orc, name):
             assert np.array_equal(v, orc["final"][net][k], equal_nan=True), (name, net, k)
     assert np.array_equal(ref["fixed_noise"], orc["fixed_noise"]), name
     assert np.array_equal(ref["samples"], orc["samples"]), name
+    assert (ref["logged"] is None) == (orc["logged"] is None), name
+    if ref["logged"] is not None:
+        assert ref["logged"].keys() == orc["logged"].keys(), (name, ref["logged"].keys(), orc["logged"].keys())
+        for mode in ref["logged"]:
+            assert ref["logged"][mode].keys() == orc["logged"][mode].keys(), (name, mode)
+            for k, v in ref["logged"][mode].items():
+                assert np.array_equal(np.array(v), np.array(orc["logged"][mode][k]), equal_nan=True), (name, mode, k)
 
 
 def write_fixture(name, case, ref):
     arrays = {"X": ref["X"], "fixed_noise": ref["fixed_noise"], "samples": ref["samples"]}
     if ref["y"] is not None:
         arrays["y"] = ref["y"]
+    if ref["Xt"] is not None:
+        arrays["X_test"], arrays["y_test"] = ref["Xt"], ref["yt"]
+    if ref["logged"] is not None:
+        for mode, per_mode in ref["logged"].items():
+            for k, v in per_mode.items():
+                arrays["logged/%s/%s" % (mode, k)] = np.asarray(v, dtype=np.float64)
     for i, z in enumerate(ref["Z"]):
         arrays["Z/%d" % i] = z
     for i, a in enumerate(ref["alpha"]):

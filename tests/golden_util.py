@@ -20,6 +20,14 @@ def load(name):
     meta = json.loads(bytes(z["meta"]).decode())
     fx = {"meta": meta, "X": z["X"], "y": z["y"] if "y" in z.files else None, "fixed_noise": z["fixed_noise"],
           "samples": z["samples"], "losses": z["losses"], "present": z["losses_present"]}
+    fx["X_test"] = z["X_test"] if "X_test" in z.files else None
+    fx["y_test"] = z["y_test"] if "y_test" in z.files else None
+    fx["logged"] = None
+    for k in z.files:
+        if k.startswith("logged/"):
+            _, mode, key = k.split("/", 2)
+            fx["logged"] = fx["logged"] or {}
+            fx["logged"].setdefault(mode, {})[key] = z[k]
     fx["Z"] = [z["Z/%d" % i] for i in range(len([k for k in z.files if k.startswith("Z/")]))]
     fx["alpha"] = [z["alpha/%d" % i] for i in range(len([k for k in z.files if k.startswith("alpha/")]))]
     for phase in ("init", "final"):

@@ -5,11 +5,9 @@ library is deterministic (no atomics), so for the clipped Wasserstein GAN everyt
 parameters, BatchNorm buffers, optimizer state, published losses and gradients.
 
 With the gradient penalty a critic weight receives four gradient contributions (fake, real and two from the
-double-backward pass) which torch's autograd engine adds in the order its scheduler reaches them; that order depends
-on sequence counters of two threads and changes between iterations and between two eager runs of one process
-(measured: eager vs eager differs by 1 ulp of the largest gradient element from the fourth iteration on), while a
-graph replays the order of the iteration it captured.  There the comparison is to 1e-5 of each tensor's largest
-magnitude, plus an exact check that the host random stream (numpy alphas) advanced identically.
+double-backward pass).  The engine's gradient ledger adds them in an order fixed by the program (engine/grads.py), not
+in the order autograd's scheduler happens to reach them, so the penalty variant is bit-reproducible as well; the
+host random stream (numpy alphas) must have advanced identically.
 """
 import copy
 
@@ -72,7 +70,7 @@ def _same(a, b, exact, what):
 @pytest.mark.parametrize("algo,steps,extra,exact", [
     ("WassersteinGAN", {"Adversariat": 3}, {"clip_val": 0.02}, True),
     ("WassersteinGAN", None, {}, True),
-    ("WassersteinGANGP", None, {}, False),
+    ("WassersteinGANGP", None, {}, True),
     ("LSGAN", {"Generator": 2}, {}, True),          # Adam: step-dependent scalars refreshed per replay
 ])
 def test_replayed_step_matches_eager(gpu, algo, steps, extra, exact):
@@ -177,14 +175,15 @@ def test_graph_follows_hyperparameter_and_shape_changes(gpu):
 
 def test_fit_through_graph_matches_fit_without(gpu):
     """The public `fit` (logging and a ragged last batch in between) gives bit-identical weights either way
-    (clipped Wasserstein GAN: see the module docstring for why the penalty variant is not bit-reproducible)."""
+    (gradient-penalty variant: four gradient contributions per critic weight, added in ledger order)."""
     import bench_configs as cfg
     X = cfg.synthetic_images(8 * 6 + 3, (3, 16, 16), seed=3)
     finals = []
     for use_graph in (False, True):
-        m = _model("WassersteinGAN", seed=9)
+        m = _model("WassersteinGANGP", seed=9)
         m.use_step_graph = use_graph
         torch.manual_seed(21)        # latent draws
+        np.random.seed(22)           # alpha draws
         m.fit(X, epochs=2, batch_size=8, print_every=None, save_losses_every=3, enable_tensorboard=False)
         finals.append(({k: v.clone() for k, v in m.generator.state_dict().items()},
                        {k: v.clone() for k, v in m.adversariat.state_dict().items()}, m.get_losses()))
@@ -192,3 +191,78 @@ def test_fit_through_graph_matches_fit_without(gpu):
         for k in a:
             assert torch.equal(a[k], b[k]), k
     assert finals[0][2] == finals[1][2]
+
+
+def test_three_runs_are_bit_identical(gpu):
+    """Same seeds, three runs in one process (the first run of a process included), eager and replayed: the gradient
+    ledger adds the four contributions to every critic weight in program order, so the gradients every optimizer step
+    receives, the losses and the final weights are the same bit patterns every time."""
+    import bench_configs as cfg
+    iters, B = 6, 8
+    data = cfg.synthetic_images(B * iters, (3, 16, 16), seed=8)
+    g = torch.Generator().manual_seed(12)
+    zs = [torch.randn(B, 16, 1, 1, generator=g) for _ in range(iters)]
+    runs = []
+    for use_graph in (False, False, True, False):
+        m = _model("WassersteinGANGP", width=16)
+        seen = []
+        plain = m._step
+
+        def step(who=None, plain=plain, m=m, seen=seen):
+            seen.append([p.grad.detach().clone() for p in m.neural_nets[who].parameters()])
+            plain(who=who)
+
+        if not use_graph:
+            m._step = step
+        batches = [m._to_device(data[i * B:(i + 1) * B]) for i in range(iters)]
+        losses, _, _ = _run(m, batches, [z.to("cuda") for z in zs], use_graph)
+        runs.append((seen, losses, _state(m)))
+    for other in runs[1:]:
+        if other[0] and runs[0][0]:
+            for k, (a, b) in enumerate(zip(runs[0][0], other[0])):
+                for i, (ga, gb) in enumerate(zip(a, b)):
+                    assert torch.equal(ga, gb), "optimizer step %d parameter %d: gradients differ between runs" % (k, i)
+        for a, b in zip(runs[0][1], other[1]):
+            for k in a:
+                assert torch.equal(a[k], b[k]) or (torch.isnan(a[k]) and torch.isnan(b[k])), k
+        for k in runs[0][2]:
+            if isinstance(runs[0][2][k], torch.Tensor):
+                assert torch.equal(runs[0][2][k], other[2][k]), k
+
+
+def test_captured_graph_survives_a_larger_scratch_buffer(gpu):
+    """The recorded kernels hold the address of the shared scratch buffer. A later eager call that needs more scratch
+    replaces the buffer; the graph must keep the one it recorded alive and still replay bit for bit."""
+    import bench_configs as cfg
+    from vegans import _hip
+    from vegans.engine import graph, ops
+    iters, B = 6, 8
+    data = cfg.synthetic_images(B * iters, (3, 16, 16), seed=8)
+    g = torch.Generator().manual_seed(12)
+    zs = [torch.randn(B, 16, 1, 1, generator=g).to("cuda") for _ in range(iters)]
+    finals = []
+    for grow in (False, True):
+        m = _model("WassersteinGANGP", width=16)
+        batches = [m._to_device(data[i * B:(i + 1) * B]) for i in range(iters)]
+        np.random.seed(77)
+        for i in range(4):
+            m.train_on_batch(batches[i], zs[i])
+        entry = next(iter(graph._graphs[m].values()))
+        assert entry.graph is not None and entry.scratch
+        if grow:
+            before = _hip.workspace(1, torch.device("cuda", 0))
+            bigger = before.numel() * 2 + (64 << 20)
+            # a weight gradient whose split-K slabs exceed the current scratch buffer
+            big = _hip.workspace(bigger, torch.device("cuda", 0))
+            assert big.data_ptr() != before.data_ptr() or big.numel() >= bigger
+            ops.fill_(big.view(torch.float32), float("nan"))        # whoever reads the NEW buffer by mistake sees NaN
+            assert any(b.data_ptr() == before.data_ptr() for b in entry.scratch)
+            del before
+            torch.cuda.empty_cache()
+        for i in range(4, iters):
+            m.train_on_batch(batches[i], zs[i])
+        torch.cuda.synchronize()
+        finals.append(_state(m))
+    for k in finals[0]:
+        if isinstance(finals[0][k], torch.Tensor):
+            assert torch.equal(finals[0][k], finals[1][k]), k

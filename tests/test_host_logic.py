@@ -100,6 +100,7 @@ _WORKER = r'''
 import os, sys
 sys.path.insert(0, os.path.join(%(root)r, "gan-pytorch_amd"))
 import torch, torch.distributed as dist
+from vegans.engine import grads
 from vegans.engine.parallel import GradReducer, chunk_bounds
 rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
 dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -108,14 +109,49 @@ net = torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.Tanh(), torch.nn.Linea
 ref = torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.Tanh(), torch.nn.Linear(5, 3), torch.nn.Tanh(), torch.nn.Linear(3, 1))
 ref.load_state_dict(net.state_dict())
 X = torch.randn(10, 6)                       # global batch of 10 rows: shards of 5 and 5; then 7 rows: 4 and 3
-red = GradReducer(list(net.parameters()), n_buckets=2, copy=lambda src, w, dst: dst.copy_(src.reshape(-1) * w))
+launches = []
+
+def cpu_summer(items, scale):                # stands in for the HIP kernel: same contract as grads.sum_into
+    launches.append(len(items))
+    out = []
+    for p, sources, dst in items:
+        acc = sources[0].reshape(-1).clone()
+        for t in sources[1:]:
+            acc = acc + t.reshape(-1)
+        acc = acc * scale
+        if dst is None:
+            dst = acc.reshape(p.shape)
+        else:
+            dst.copy_(acc)
+        out.append(dst)
+    return out
+
+params = list(net.parameters())
+red = GradReducer(params, n_buckets=2, summer=cpu_summer)
 assert len(red.buckets) >= 2
-for rows in (10, 7):
+for rows in (10, 7, 7):
     lo, hi = chunk_bounds(rows, world, rank)
-    for p in net.parameters():
+    mid = (lo + hi) // 2
+    for p in params:
         p.grad = None
-    red.arm((hi - lo) / float(rows))
-    net(X[lo:hi]).mean().backward()          # local mean over this rank's rows
+    n_local = hi - lo
+    # two contributions per parameter (two halves of the shard; their sum is the gradient of the local mean), handed
+    # over in a different order on every rank and every pass: the ledger's label order must decide the sum
+    parts = []
+    for k, (a, b) in enumerate(((lo, mid), (mid, hi))):
+        g = torch.autograd.grad(net(X[a:b]).sum() / n_local, params)
+        parts += [((k + 1,), p, t) for p, t in zip(params, g)]
+    if (rank + rows) %% 2:
+        parts.reverse()
+    with red.open(n_local / float(rows)) as ledger:
+        assert grads.collecting()
+        for label, p, t in parts:
+            assert grads.route(p, label, t) is None
+        for p in params:                                     # label order, whatever the arrival order
+            got = ledger.sources(p) if id(p) not in ledger.done else None
+            if got is not None:
+                assert len(got) == 2
+    assert not grads.collecting()
     red.finish()
     for p in ref.parameters():
         p.grad = None
@@ -123,10 +159,60 @@ for rows in (10, 7):
     for p, q in zip(net.parameters(), ref.parameters()):
         assert torch.allclose(p.grad, q.grad, rtol=1e-5, atol=1e-7), (rows, (p.grad - q.grad).abs().max())
         assert p.grad.shape == q.shape
+        bi, off = red.where[id(p)]
+        assert p.grad.data_ptr() == red.flat[bi][off:].data_ptr()      # the optimizer reads the bucket itself
+# the third pass knew every parameter's contribution count from the second: parameters were summed one by one as they
+# became complete (so their buckets could be reduced during the backward pass), not in one launch at the end
+assert launches[-len(params):] == [1] * len(params), launches
+# a contribution that arrives after its parameter was handed over must fail loudly, not be dropped
+for p in params:
+    p.grad = None
+with red.open(1.0) as ledger:
+    for label, p, t in parts:
+        grads.route(p, label, t)
+    try:
+        grads.route(params[0], (9,), parts[0][2])
+        raise SystemExit("late contribution was accepted")
+    except Exception as exc:
+        assert "after its parameter" in str(exc), exc
+red.finish()
 dist.barrier()
 dist.destroy_process_group()
 print("rank", rank, "ok")
 '''
+
+
+def test_ledger_sums_in_label_order_on_cpu():
+    """The ledger's ordering logic without a GPU: contributions deposited in any order are summed in label order, a
+    gradient left from an earlier pass comes first, parameters outside the ledger go back to autograd."""
+    from vegans.engine import grads
+    p = torch.nn.Parameter(torch.zeros(3))
+    q = torch.nn.Parameter(torch.zeros(2))
+    seen = []
+
+    def summer(items, scale):
+        out = []
+        for par, sources, dst in items:
+            seen.append([float(t[0]) for t in sources])
+            acc = sources[0].clone()
+            for t in sources[1:]:
+                acc = acc + t
+            out.append(acc * scale)
+        return out
+
+    p.grad = torch.full((3,), 7.0)
+    with grads.Ledger([p], summer=summer):
+        assert grads.route(p, (5, 1), torch.full((3,), 3.0)) is None
+        assert grads.route(p, (5,), torch.full((3,), 2.0)) is None
+        assert grads.route(p, (2, 0, 1), torch.full((3,), 1.0)) is None
+        t = torch.ones(2)
+        assert grads.route(q, (1,), t) is t            # not this ledger's parameter: autograd keeps it
+        assert grads.route(p, (9,), None) is None
+    assert seen == [[7.0, 1.0, 2.0, 3.0]]
+    assert torch.equal(p.grad, torch.full((3,), 13.0))
+    assert not grads.collecting()
+    a, b = grads.ticket(), grads.ticket()
+    assert a < b and a + (0,) < b
 
 
 def test_grad_reducer_two_ranks_gloo(tmp_path):

@@ -632,3 +632,77 @@ def test_clamp_fused_and_bit_exact(gpu):
     clipped = pr.detach().abs() >= np.float32(0.01)
     assert torch.equal(out[clipped], pr.detach()[clipped])      # clamped entries are bit-identical
     _close(out, pr, tol=2e-6, what="clamped rmsprop")
+
+
+def test_grad_sum_multi_adds_in_the_given_order(gpu):
+    """vg_grad_sum_multi: out = scale * (((s0 + s1) + s2) + ...), bit for bit the left-to-right f32 sum, for many
+    tensors in one launch (odd sizes take the scalar path), in place into the first source, and chained beyond eight
+    sources."""
+    from vegans.engine import grads
+    g = torch.Generator().manual_seed(3)
+    shapes = [(64, 4, 4, 16), (7,), (33, 5), (128,), (3, 3, 3, 3)]
+    counts = [4, 1, 3, 11, 2]
+    items, want = [], []
+    for shape, k in zip(shapes, counts):
+        srcs = [(torch.randn(shape, generator=g) * 10.0 ** (i % 5 - 2)) for i in range(k)]
+        acc = srcs[0].clone()
+        for t in srcs[1:]:
+            acc = acc + t
+        want.append(acc * np.float32(0.25))
+        p = torch.empty(shape, device=gpu)
+        items.append((p, [t.to(gpu) for t in srcs], None))
+    got = grads.sum_into(items, 0.25)
+    for (p, srcs, _), out, ref in zip(items, got, want):
+        assert out.data_ptr() == srcs[0].data_ptr()          # in place into the first contribution
+        assert torch.equal(out.cpu(), ref)
+    # separate outputs (data-parallel bucket slots), scale 1: a single source is copied
+    outs = [torch.full(s, 9.0, device=gpu) for s in shapes[:2]]
+    srcs = [[torch.randn(s, generator=g).to(gpu) for _ in range(k)] for s, k in zip(shapes[:2], (3, 1))]
+    res = grads.sum_into([(o, ss, o) for o, ss in zip(outs, srcs)], 1.0)
+    assert torch.equal(res[0].cpu(), ((srcs[0][0].cpu() + srcs[0][1].cpu()) + srcs[0][2].cpu()))
+    assert torch.equal(res[1].cpu(), srcs[1][0].cpu())
+
+
+def test_losses_on_strided_predictions(gpu):
+    """A prediction that is a channel slice of a wider activation (not one dense block) must be compacted before the
+    loss kernels walk it as flat memory."""
+    from vegans.engine import ops
+    g = torch.Generator().manual_seed(5)
+    wide = torch.rand(6, 5, 3, 3, generator=g) * 0.8 + 0.1
+    wide_d = ops.to_nhwc(wide.to(gpu))
+    for name, fn, ref in (("mean", lambda p: ops.loss_mean(p, -1.0), lambda p: -p.mean()),
+                          ("bce", lambda p: ops.loss_bce(p, 1), lambda p: F.binary_cross_entropy(p, torch.ones_like(p))),
+                          ("mse", lambda p: ops.loss_mse(p, 0), lambda p: (p ** 2).mean())):
+        base = wide_d.clone().requires_grad_(True)
+        pred = base[:, 1:3]                                   # NHWC channel slice: strided
+        assert not pred.is_contiguous() and not pred.is_contiguous(memory_format=torch.channels_last)
+        loss = fn(pred)
+        loss.backward()
+        rb = wide.clone().requires_grad_(True)
+        rl = ref(rb[:, 1:3])
+        rl.backward()
+        _close(loss, rl, 2e-5, name)
+        _close(base.grad, rb.grad, 2e-5, name + " grad")
+    a = wide_d.clone().requires_grad_(True)
+    l1 = ops.loss_l1(a[:, 0:2], wide_d[:, 3:5])
+    l1.backward()
+    ra = wide.clone().requires_grad_(True)
+    rl = (ra[:, 0:2] - wide[:, 3:5]).abs().mean()
+    rl.backward()
+    _close(l1, rl, 2e-5, "l1")
+    _close(a.grad, ra.grad, 2e-5, "l1 grad")
+
+
+def test_clamp_reaches_parameters_without_gradient(gpu):
+    """The reference clamps every critic parameter after the critic's step (WassersteinGAN.py:78-79), also those that
+    received no gradient in this step."""
+    from vegans.engine import optim as hip_optim
+    used = torch.nn.Parameter(torch.tensor([0.5, -0.5, 0.001], device=gpu))
+    unused = torch.nn.Parameter(torch.tensor([0.3, -0.2, 0.005, float("nan")], device=gpu))
+    opt = torch.optim.RMSprop([used, unused], lr=1e-3)
+    used.grad = torch.ones(3, device=gpu)
+    hip_optim.fused_step(opt, clamp=(-0.01, 0.01))
+    got = unused.detach().cpu()
+    assert got[:3].tolist() == [float(np.float32(0.01)), float(np.float32(-0.01)), float(np.float32(0.005))]
+    assert torch.isnan(got[3])
+    assert float(used.detach().abs().max()) == float(np.float32(0.01))

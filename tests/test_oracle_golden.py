@@ -22,7 +22,15 @@ def test_oracle_reproduces_reference_fixture(name):
     # the constructor consumed the RNG exactly like the reference did
     np.testing.assert_array_equal(o.fixed_noise.detach().numpy(), fx["fixed_noise"])
     hist = o.fit(fx["X"], fx["y"], epochs=1, batch_size=case["batch"], steps=case.get("steps"),
-                 latents=[torch.from_numpy(z) for z in fx["Z"]], alphas=list(fx["alpha"]))
+                 latents=[torch.from_numpy(z) for z in fx["Z"]], alphas=list(fx["alpha"]), X_test=fx["X_test"],
+                 y_test=fx["y_test"], **case.get("fit", {}))
+    if fx["logged"] is not None:      # values of the logging passes (AbstractGenerativeModel.py:329-351)
+        assert set(o.logged_losses) == set(fx["logged"])
+        for mode, per_mode in fx["logged"].items():
+            for k, want in per_mode.items():
+                got = np.asarray(o.logged_losses[mode][k], dtype=np.float64)
+                assert got.shape == want.shape, (mode, k)
+                np.testing.assert_allclose(got, want, rtol=1e-5, atol=1e-6, equal_nan=True, err_msg="%s/%s" % (mode, k))
     rows = gu.loss_rows(fx)
     assert [w for w, _ in hist] == [w for w, _ in rows]
     for (who, got), (_, want) in zip(hist, rows):
