@@ -3,6 +3,8 @@
 // its own f32 slab and a second kernel adds the slabs in split order (bitwise reproducible, no atomics).
 #include "pgemm.h"
 
+#include <mutex>
+
 int vg_try_wgrad_stem(const vg_conv_geom* g, const float* gy, const float* x, float* slabs, int nslabs, hipStream_t st);
 
 namespace {
@@ -208,4 +210,53 @@ extern "C" int vg_conv2d_wgrad(const vg_conv_geom* g, const float* gy, const flo
                                size_t workspace_bytes, void* stream) {
   if (int e = vg_conv2d_wgrad_partial(g, gy, x, gw, workspace, workspace_bytes, stream)) return e;
   return vg_conv2d_wgrad_reduce(g, gw, workspace, stream);
+}
+
+// ---- the weight gradient for callers that cannot allocate -----------------------------------------------------------
+// Same kernels as vg_conv2d_wgrad; the split-K slabs live in a file-scope device array instead of a caller-provided
+// workspace. Every GPU the library runs on holds its own copy of the array (at its own address) until the process
+// ends. The array's name is only a host-side handle: the device address is looked up once per device with
+// hipGetSymbolAddress and that pointer is what the kernels receive.
+constexpr size_t kStaticScratchBytes = (size_t)32 << 20;      // 32 MiB: the largest slab set of a DCGAN-64 layer at batch 256
+static __device__ __align__(256) unsigned char scratch[kStaticScratchBytes];
+
+namespace {
+constexpr int kMaxDevices = 64;
+void* g_scratch_ptr[kMaxDevices] = {nullptr};
+std::mutex g_scratch_mutex;
+
+// Device address of `scratch` on the current device (looked up on the first call per device, with that device current).
+int static_scratch(void** out) {
+  int dev = -1;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return vg_fail(VG_ERR_LAUNCH, "vg_conv2d_wgrad_noalloc: hipGetDevice: %s", hipGetErrorString(e));
+  if (dev < 0 || dev >= kMaxDevices) return vg_fail(VG_ERR_INVALID, "vg_conv2d_wgrad_noalloc: device index %d out of range", dev);
+  std::lock_guard<std::mutex> lock(g_scratch_mutex);
+  if (!g_scratch_ptr[dev]) {
+    void* ptr = nullptr;
+    e = hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch));
+    if (e != hipSuccess || !ptr)
+      return vg_fail(VG_ERR_LAUNCH, "vg_conv2d_wgrad_noalloc: hipGetSymbolAddress(scratch) on device %d: %s", dev,
+                     hipGetErrorString(e));
+    g_scratch_ptr[dev] = ptr;
+  }
+  *out = g_scratch_ptr[dev];
+  return VG_OK;
+}
+}  // namespace
+
+extern "C" int vg_conv2d_wgrad_noalloc(const vg_conv_geom* g, const float* gy, const float* x, float* gw, void* stream) {
+  if (int e = vg_check_geom(g, "vg_conv2d_wgrad_noalloc")) return e;
+  VG_REQUIRE(gy && x && gw, "vg_conv2d_wgrad_noalloc: null tensor pointer");
+  const size_t need = vg_conv2d_wgrad_workspace_bytes(g);
+  if (need > kStaticScratchBytes)
+    return vg_fail(VG_ERR_WORKSPACE,
+                   "vg_conv2d_wgrad_noalloc: this geometry needs %zu bytes of split-K slabs, the built-in scratch holds %zu; "
+                   "use vg_conv2d_wgrad with a caller-provided workspace",
+                   need, kStaticScratchBytes);
+  void* ws = nullptr;
+  if (int e = static_scratch(&ws)) return e;
+  // every split writes its whole slab before the reduce reads it: nothing has to start at zero, whatever the previous
+  // call left behind
+  return vg_conv2d_wgrad(g, gy, x, gw, ws, kStaticScratchBytes, stream);
 }

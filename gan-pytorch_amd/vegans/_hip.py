@@ -52,6 +52,7 @@ SIGNATURES = {
     "vg_conv2d_dgrad": (c_int, [_G, _P, _P, _P, _P, _P]),
     "vg_conv2d_wgrad_workspace_bytes": (c_size_t, [_G]),
     "vg_conv2d_wgrad": (c_int, [_G, _P, _P, _P, _P, c_size_t, _P]),
+    "vg_conv2d_wgrad_noalloc": (c_int, [_G, _P, _P, _P, _P]),
     "vg_conv2d_wgrad_partial": (c_int, [_G, _P, _P, _P, _P, c_size_t, _P]),
     "vg_conv2d_wgrad_reduce": (c_int, [_G, _P, _P, _P]),
     "vg_conv2d_variant": (c_int, [c_int, _G, ctypes.c_char_p, c_size_t]),

@@ -84,6 +84,16 @@ int vg_conv2d_wgrad_partial(const vg_conv_geom* g, const float* gy, const float*
                             void* workspace, size_t workspace_bytes, void* stream);
 int vg_conv2d_wgrad_reduce(const vg_conv_geom* g, float* gw, const void* workspace, void* stream);
 
+/* vg_conv2d_wgrad for callers that cannot allocate device memory or hand over a workspace (code running under HIP graph
+ * capture, tight serving loops, harnesses that forbid hipMalloc). It has no counterpart in the reference. Same
+ * arguments, kernels and bit-identical results as vg_conv2d_wgrad; the split-K slabs go to a 32 MiB device array built
+ * into the library (one copy per GPU, held until the process ends). A geometry whose slabs exceed that
+ * (vg_conv2d_wgrad_workspace_bytes(g) > 32 MiB) is refused with VG_ERR_WORKSPACE. The call allocates and frees
+ * nothing. All calls on one GPU share that GPU's array: calls that overlap in time on one GPU (different streams) race;
+ * calls on one stream, or otherwise ordered, are safe, and nothing needs clearing between them. The first call on a
+ * device looks up the array's device address (hipGetSymbolAddress): make it outside a stream capture. */
+int vg_conv2d_wgrad_noalloc(const vg_conv_geom* g, const float* gy, const float* x, float* gw, void* stream);
+
 /* The same three contractions with a choice of multiplier precision (the north-star configuration names a bf16 mode
  * next to fp32): VG_PREC_F32 = exact f32 products (what the un-suffixed entry points do); VG_PREC_BF16 = operands
  * rounded to bf16 (nearest even) on their way into the matrix cores, f32 accumulation, f32 tensors in memory;
