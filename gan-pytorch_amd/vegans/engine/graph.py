@@ -96,6 +96,7 @@ class _StepGraph:
         self.losses = None
         self.grads = None
         self.scratch = None
+        self.replays = 0
 
     def carve(self, shape):
         """A static buffer for a host input. It must not come from the graph's own memory pool: the pool hands a block
@@ -185,6 +186,7 @@ class _StepGraph:
         model._losses = dict(self.losses)
         for p, g in self.grads:
             p.grad = g
+        self.replays += 1
 
 
 _GRAPHABLE_OPTIMIZERS = (torch.optim.RMSprop, torch.optim.SGD, torch.optim.Adam, torch.optim.AdamW)
@@ -267,6 +269,11 @@ def run_step(model, body, inputs):
                           (type(exc).__name__, exc))
             return body(*inputs)
     entry.replay(model, inputs)
+
+
+def replays(model):
+    """How many training iterations of `model` were replayed from captured HIP graphs so far."""
+    return sum(e.replays for e in _graphs.get(model, {}).values())
 
 
 def reset(model):

@@ -537,9 +537,34 @@ def _act_args(y, act, slope):
     return _ptr(y), act, c_float(slope)
 
 
+class AddFn(Function):
+    """a + b for two activations of one shape (a sum the engine wants to own rather than leave to autograd's input
+    buffers)."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        a = _dense_like(a)
+        b = _match_layout(_dense_like(b), a)
+        if a.shape != b.shape:
+            raise _hip.HipError("sum operands differ in shape: %s vs %s" % (tuple(a.shape), tuple(b.shape)))
+        out = torch.empty_like(a)
+        call("vg_add", _ptr(a), _ptr(b), _ptr(out), c_size_t(a.numel()), _stream())
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        return g, g
+
+
 class BatchNormTrainFn(Function):
     """Training-mode batch norm, optionally with a ReLU / LeakyReLU applied in the same pass (`act`). With a fused
-    activation the output doubles as the slope mask of the backward pass, so no pre-activation tensor exists."""
+    activation the output doubles as the slope mask of the backward pass, so no pre-activation tensor exists.
+
+    Returns (y, tap). `tap` is an alias of the input that exists for the second derivative only: the first-order
+    backward below is itself an operator of x (through the batch statistics), and when it is differentiated again
+    (gradient penalty) its gradient with respect to x has to be added to the gradient that arrives through y. The
+    backward operator therefore reads x through `tap`, both gradients arrive HERE, and the sum is formed by the engine
+    (one kernel, fixed operand order) instead of by an accumulation inside autograd's scheduler."""
 
     @staticmethod
     def forward(ctx, x, gamma, beta, running_mean, running_var, momentum, eps, act, slope, batches_tracked):
@@ -558,14 +583,23 @@ class BatchNormTrainFn(Function):
              act, c_float(slope), _stream())
         ctx.act, ctx.slope = act, slope
         ctx.label = grads.ticket()
-        ctx.save_for_backward(x_in, gamma, beta, mean, invstd, y if act != _hip.ACT_NONE else None)
-        return y
+        tap = x_in.view_as(x_in)
+        ctx.save_for_backward(tap, gamma, beta, mean, invstd, y if act != _hip.ACT_NONE else None)
+        ctx.set_materialize_grads(False)
+        return y, tap
 
     @staticmethod
-    def backward(ctx, gy):
-        x, gamma, beta, mean, invstd, y = ctx.saved_tensors
+    def backward(ctx, gy, gtap):
+        tap, gamma, beta, mean, invstd, y = ctx.saved_tensors
         lab = ctx.label
-        gx, ggamma, gbeta = BatchNormBwdFn.apply(gy, x, gamma, mean, invstd, y, ctx.act, ctx.slope, lab + (0,))
+        gx = ggamma = gbeta = None
+        if gy is not None:
+            # the activation's output only supplies a piecewise-constant mask: detached, so the second derivative does
+            # not come back to this operator through it
+            mask = y.detach() if y is not None else None
+            gx, ggamma, gbeta = BatchNormBwdFn.apply(gy, tap, gamma, mean, invstd, mask, ctx.act, ctx.slope, lab + (0,))
+        if gtap is not None:
+            gx = gtap if gx is None else AddFn.apply(gx, gtap)
         return (gx, grads.route(gamma, lab, ggamma) if gamma is not None else None,
                 grads.route(beta, lab, gbeta) if beta is not None else None,
                 None, None, None, None, None, None, None)
@@ -670,7 +704,7 @@ def batch_norm(x, gamma, beta, running_mean, running_var, training, momentum, ep
         if batches_tracked is not None and (batches_tracked.dtype != torch.int64 or not batches_tracked.is_cuda):
             raise _hip.HipError("num_batches_tracked must be an int64 tensor on the GPU")
         return BatchNormTrainFn.apply(x, gamma, beta, running_mean, running_var, momentum, eps, act, float(slope),
-                                      batches_tracked)
+                                      batches_tracked)[0]
     return BatchNormEvalFn.apply(x, gamma, beta, running_mean, running_var, eps, act, float(slope))
 
 

@@ -517,6 +517,11 @@ def test_gradient_penalty_with_bn_critic_double_backward(gpu, fused):
         if b.grad is None:
             assert a.grad is None or float(a.grad.abs().max()) < 1e-6
             continue
+        if a.grad is None:
+            # a shift in front of a leaky relu reaches the penalty through the piecewise-constant slope mask only:
+            # torch reports an all-zero gradient, the engine none at all
+            assert float(b.grad.abs().max()) == 0.0, name
+            continue
         _close(a.grad, b.grad, tol=1e-3, what="penalty grad " + name)
 
 
