@@ -677,3 +677,112 @@ def test_fixture_cases_teacher_forced_vs_oracle(gpu, name, capsys):
         print("\n%-20s teacher-forced, %d sub-steps: worst loss error %.2e of its own value, worst outlier share %.2e"
               % (name, n_sub, stats["loss"], stats["share"]))
     assert not stats["problems"], "\n".join(stats["problems"][:40])
+
+
+def test_trained_state_loads_into_stock_torch(gpu):
+    """After an engine `fit`, the user's modules handed back as stock torch classes (`modules.unbind`) carry the trained
+    values: their `state_dict()` loads into fresh stock modules on the CPU, which then reproduce the reference
+    fixture's eval-mode samples, and the optimizers' `state_dict()` loads into stock torch optimizers that can keep
+    training on the CPU (reference: whole-object save/load, AbstractGenerativeModel.py:534-562)."""
+    from vegans.engine import modules
+    name = "wgangp_dcgan16"
+    fx = gu.load(name)
+    case = fx["meta"]
+    nets = gu.build_nets(case)
+    torch.manual_seed(case["seed"])
+    np.random.seed(case["seed"])
+    model = _build_model(case, nets)
+    _inject(model, [torch.from_numpy(z) for z in fx["Z"]], fx["alpha"], [])
+    _fit(model, case, fx["X"], fx["y"])
+    G_trained = modules.unbind(model.generator.network)
+    D_trained = modules.unbind(model.adversariat.network)
+    assert type(G_trained[0]) is torch.nn.ConvTranspose2d and type(D_trained[0]) is torch.nn.Conv2d
+    G_cpu, D_cpu, _ = gu.build_nets(case)
+    G_cpu.load_state_dict({k: v.cpu() for k, v in G_trained.state_dict().items()})
+    D_cpu.load_state_dict({k: v.cpu() for k, v in D_trained.state_dict().items()})
+    for k, v in G_cpu.state_dict().items():
+        assert v.is_contiguous(), k                       # plain NCHW tensors, whatever layout the engine kept
+    G_cpu.eval()
+    with torch.no_grad():
+        samples = G_cpu(torch.from_numpy(fx["fixed_noise"])).numpy()
+    _close(samples, fx["samples"], REL, 1e-1, "stock torch generator with engine-trained weights")
+    # optimizer state: same keys and shapes as a stock RMSprop's, loadable, and usable for a CPU step
+    for net_cpu, key in ((G_cpu, "Generator"), (D_cpu, "Adversariat")):
+        sd = model.optimizers[key].state_dict()
+        opt = torch.optim.RMSprop(net_cpu.parameters(), **case["optim_kwargs"][key])
+        opt.load_state_dict(sd)
+        for p in net_cpu.parameters():
+            st = opt.state[p]
+            assert float(st["step"]) == len(fx["Z"])
+            assert st["square_avg"].shape == p.shape and torch.isfinite(st["square_avg"]).all()
+            p.grad = torch.ones_like(p)
+        net_cpu.train()
+        opt.step()
+    modules.bind(model.generator.network)
+    modules.bind(model.adversariat.network)
+
+
+def test_image_logging_and_summary(gpu, tmp_path, capsys):
+    """`save_images_every`, `save_model_every` and `summary()` (AbstractGenerativeModel.py:337-342, 407-432, 628-645):
+    image grids of the fixed-noise samples and the loss plot land in the run folder, periodic checkpoints load, and the
+    summary lists every network."""
+    import matplotlib
+    matplotlib.use("Agg")
+    import bench_configs as cfg
+    import vegans.GAN as gan
+    G = cfg.seeded_init(cfg.dcgan_generator(nz=16, ngf=8, nc=3, size=16), 1, 0.08)
+    D = cfg.seeded_init(cfg.dcgan_critic(ndf=8, nc=3, size=16), 2, 0.08)
+    folder = str(tmp_path / "run")
+    m = gan.WassersteinGANGP(G, D, x_dim=(3, 16, 16), z_dim=(16, 1, 1), folder=folder, fixed_noise_size=4)
+    X = cfg.synthetic_images(32, (3, 16, 16), seed=2)
+    m.fit(X, epochs=1, batch_size=8, print_every=None, save_losses_every=1, save_images_every=2, save_model_every=4,
+          enable_tensorboard=False)
+    import os
+    images = sorted(os.listdir(m.folder + "images"))
+    assert images == ["image_0.png", "image_2.png", "image_4.png"], images
+    assert all(os.path.getsize(m.folder + "images/" + f) > 1000 for f in images)
+    assert os.path.getsize(m.folder + "losses.png") > 1000
+    assert os.listdir(m.folder + "models") == ["model_4.torch"]
+    loaded = gan.WassersteinGANGP.load(m.folder + "models/model_4.torch")
+    assert loaded.generate(z=loaded.fixed_noise).shape == (4, 3, 16, 16)
+    capsys.readouterr()
+    m.summary()
+    text = capsys.readouterr().out
+    assert "Generator" in text and "Adversariat" in text and "Total params" in text and "ConvTranspose2d" in text
+    m.summary(save=True)
+    assert "Total params" in open(m.folder + "summary.txt").read()
+
+
+def test_lsgan_full_width_dcgan128_vs_oracle(gpu, capsys):
+    """The DCGAN-128 configuration (LSGAN, Adam defaults, ngf = ndf = 64: 1024-channel layers, 3x128x128, z = 100) at a
+    batch the CPU oracle finishes in seconds: two iterations, teacher-forced before every sub-step, losses at 1e-4 of
+    their own value (floor 1e-2), parameters and buffers at 1e-4 of their tensor's scale with the outlier budget of
+    the fixture test."""
+    import bench_configs as cfg
+
+    def nets():
+        return (cfg.dcgan_init(cfg.dcgan_generator(100, 64, 3, 128), 1),
+                cfg.dcgan_init(cfg.dcgan_critic(64, 3, 128, sigmoid=True), 2))
+
+    oracle, model = _oracle_and_model("lsgan", "LSGAN", nets, (3, 128, 128), (100, 1, 1), None)
+    B = 8
+    model.use_step_graph = False
+    model._create_steps(None)
+    model.train()
+    oracle._set_mode(True)
+    stats = {"loss": 0.0, "share": 0.0, "outliers": {}}
+    zgen = torch.Generator().manual_seed(10)
+    for it in range(2):
+        X = torch.from_numpy(cfg.synthetic_images(B, (3, 128, 128), seed=60 + it))
+        Z = torch.randn(B, 100, 1, 1, generator=zgen)
+        Xd, Zd = model._to_device(X.numpy()), Z.to("cuda")
+        for who in ("Generator", "Adversariat"):
+            _sync_from_oracle(oracle, model)
+            want = oracle.sub_step(who, X, Z.clone(), None, None)
+            got = _engine_sub_step(model, who, Xd, Zd)
+            _compare_sub_step("iteration %d %s" % (it, who), want, got, oracle, model, ["Generator", "Adversariat"], {},
+                              1e-2, 2e-3, stats)
+    with capsys.disabled():
+        print("\nDCGAN-128 LSGAN/Adam full width, batch %d, teacher-forced: worst loss error %.2e of its own value, worst "
+              "outlier share %.2e" % (B, stats["loss"], stats["share"]))
+    assert not stats["problems"], "\n".join(stats["problems"][:40])

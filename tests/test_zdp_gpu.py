@@ -107,6 +107,42 @@ for name, net_o in oracle.nets.items():
     problems += gu.compare_network(got, want, network, 1e-4, 2e-2, name)
 print("rank %%d batch-norm data parallel vs two-device oracle: %%d problems" %% (rank, len(problems)))
 assert not problems, "\n".join(problems)
+
+# ---- LSGAN with Adam (device-side step scalars refreshed per replay) through the graph chain -------------------------
+def ls_nets():
+    return (cfg.seeded_init(cfg.dcgan_generator(nz=16, ngf=8, nc=3, size=16), 1, 0.08),
+            cfg.seeded_init(cfg.dcgan_critic(ndf=8, nc=3, size=16, sigmoid=True), 2, 0.08))
+
+akw = {"Generator": {"lr": 2e-4, "betas": (0.5, 0.999)}, "Adversariat": {"lr": 2e-4, "betas": (0.5, 0.999)}}
+torch.manual_seed(3); np.random.seed(3)
+Go, Do = ls_nets()
+oracle = OracleGAN("lsgan", Go, Do, (3, 16, 16), (16, 1, 1), optim_kwargs=copy.deepcopy(akw), fixed_noise_size=4)
+hist = oracle.fit(Xb, None, epochs=1, batch_size=B, latents=[z.clone() for z in Zs], shards=world)
+torch.manual_seed(3); np.random.seed(3)
+Gm, Dm = ls_nets()
+with contextlib.redirect_stdout(io.StringIO()):
+    ml = gan.LSGAN(Gm, Dm, x_dim=(3, 16, 16), z_dim=(16, 1, 1), folder=None, fixed_noise_size=4, ngpu=world,
+                   optim_kwargs=copy.deepcopy(akw))
+zi = iter(Zs)
+ml.sample = lambda n: next(zi)[:n].to("cuda").requires_grad_(True)
+with contextlib.redirect_stdout(io.StringIO()):
+    ml.fit(Xb, epochs=1, batch_size=B, print_every=None, save_losses_every=None, enable_tensorboard=False)
+from vegans.engine import graph
+full = [e for e in graph._graphs[ml].values() if e.graph is not None]
+assert len(full) == 1 and not full[0].failed and full[0].replays == iters - 2, [(e.eager_calls, e.failed, e.replays) for e in graph._graphs[ml].values()]
+problems = []
+for name, net_o in oracle.nets.items():
+    want = {k: v.detach().numpy() for k, v in net_o.state_dict().items()}
+    network = ml.neural_nets[name].network
+    got = network.state_dict()
+    if rank != 0:
+        want = {k: v for k, v in want.items() if "running_" not in k}
+        got = {k: v for k, v in got.items() if "running_" not in k}
+    problems += gu.compare_network(got, want, network, 1e-4, 2e-2, name)
+    for po, pm in zip(net_o.parameters(), network.parameters()):
+        assert float(ml.optimizers[name].state[pm]["step"]) == float(oracle.optimizers[name].state[po]["step"]) == iters
+print("rank %%d LSGAN/Adam data parallel vs two-device oracle: %%d problems" %% (rank, len(problems)))
+assert not problems, "\n".join(problems)
 dist.barrier(); dist.destroy_process_group()
 print("rank", rank, "ok")
 '''
