@@ -19,3 +19,21 @@ def gpu():
     if not torch.cuda.is_available():
         pytest.fail("test marked gpu but no GPU is visible")
     return torch.device("cuda:0")
+
+
+def pytest_terminal_summary(terminalreporter):
+    """Free-running parameter comparisons allow a small share of elements beyond 1e-4 (golden_util.compare_network):
+    say how much of that allowance the run actually used, so a regression inside the budget is visible."""
+    try:
+        import golden_util as gu
+    except ImportError:
+        return
+    rows = gu.OUTLIER_REPORT
+    if not rows:
+        return
+    used = [(n / float(size), label, key, n, size) for label, key, n, size in rows if n]
+    terminalreporter.write_line("parameter tensors compared free-running: %d, with elements beyond tolerance: %d "
+                                "(allowance: %.1f%% of a tensor, at least one element)" %
+                                (len(rows), len(used), 100 * gu.OUTLIER_FRACTION))
+    for share, label, key, n, size in sorted(used, reverse=True)[:8]:
+        terminalreporter.write_line("   %-12s %-28s %d of %d (%.2f%%)" % (label, key, n, size, 100 * share))

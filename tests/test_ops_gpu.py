@@ -1,7 +1,8 @@
 """Operator-level parity of the HIP kernels (called through the C ABI via the engine's autograd Functions)
 against plain torch fp32 on the CPU.  Tolerances: the kernels are exact-f32 FMA chains in a different
 summation order than torch's CPU kernels, so outputs agree to ~1e-6 relative to the operand scale; the tests
-use rtol 2e-4 / atol scaled by the reduction length."""
+use 2e-5 of the reference tensor's largest magnitude for first-order quantities (forward, input and weight
+gradients) and 1e-4 for second-order ones (penalty gradients)."""
 import numpy as np
 import pytest
 import torch
@@ -10,7 +11,7 @@ import torch.nn.functional as F
 pytestmark = pytest.mark.gpu
 
 
-def _close(a, b, tol=2e-4, what=""):
+def _close(a, b, tol=2e-5, what=""):
     a = a.detach().cpu().double()
     b = b.detach().cpu().double()
     assert a.shape == b.shape, (what, a.shape, b.shape)
@@ -384,7 +385,7 @@ def test_activations_first_and_second_order(gpu, act):
     if act in ("tanh", "sigmoid"):
         (gxr ** 2).sum().backward()
         ops.loss_mse(gxd, 0.0).backward()   # mean(gx^2): same second-order path up to the 1/n factor
-        _close(xd.grad * gxd.numel(), xr.grad, tol=5e-4, what="act second order")
+        _close(xd.grad * gxd.numel(), xr.grad, tol=1e-4, what="act second order")
 
 
 def test_losses(gpu):
@@ -522,7 +523,7 @@ def test_gradient_penalty_with_bn_critic_double_backward(gpu, fused):
             # torch reports an all-zero gradient, the engine none at all
             assert float(b.grad.abs().max()) == 0.0, name
             continue
-        _close(a.grad, b.grad, tol=1e-3, what="penalty grad " + name)
+        _close(a.grad, b.grad, tol=1e-4, what="penalty grad " + name)
 
 
 @pytest.mark.parametrize("act,slope", [("lrelu", 0.2), ("relu", 0.0)])
@@ -573,7 +574,7 @@ def test_stem_convolution_with_fused_activation(gpu, act, slope):
     _close(out_f, out_r, what="critic output")
     _close(gx_f, gx_r, what="d critic / d input")
     for name, a, b in zip(("w1", "b1", "w2"), gf, gr):
-        _close(a, b, tol=1e-3, what="gradient " + name)
+        _close(a, b, tol=1e-4, what="gradient " + name)
     assert torch.equal(out_f, out_s) and torch.equal(gx_f, gx_s)
     for a, b in zip(gf, gs):
         assert torch.equal(a, b)
