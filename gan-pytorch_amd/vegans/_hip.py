@@ -183,8 +183,10 @@ def workspace_buffers():
 
 
 def workspace(nbytes, device):
-    """Grow-only scratch buffer per device; all kernels of one rank run on one stream, so they can share it."""
-    key = device.index if device.index is not None else torch.cuda.current_device()
+    """Grow-only scratch buffer per device and stream role (the launch stream and each side stream of
+    engine/streams.py have one of their own): kernels that may run concurrently never share scratch."""
+    from .engine import streams
+    key = (device.index if device.index is not None else torch.cuda.current_device(), streams.role())
     buf = _workspace.get(key)
     if buf is None or buf.numel() < nbytes:
         if _workspace_frozen:

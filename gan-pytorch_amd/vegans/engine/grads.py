@@ -25,6 +25,7 @@ import torch
 
 from .. import _hip
 from .._hip import _stream, call
+from . import streams
 
 MAX_SOURCES = 8          # contributions one kernel launch adds per tensor (more are chained)
 
@@ -120,6 +121,7 @@ class Ledger:
         self.sink = sink
         self.summer = summer if summer is not None else sum_into    # host-logic tests pass a CPU stand-in
         self.done = set()
+        self.events = []     # completion events of contributions produced on side streams
 
     def __enter__(self):
         global _active
@@ -145,6 +147,11 @@ class Ledger:
             raise _hip.HipError("a gradient contribution arrived after its parameter's bucket had been handed to the "
                                 "all-reduce: the model's backward graph changed between two iterations")
         self.entries.setdefault(key, []).append((label, grad.detach()))
+        if grad.is_cuda and streams.forked():
+            # produced on whatever stream this backward node runs on; the summation waits for it (flush)
+            ev = torch.cuda.Event()
+            ev.record()
+            self.events.append(ev)
         if self.sink is not None:
             self.sink.deposited(self, param, len(self.entries[key]))
 
@@ -157,6 +164,11 @@ class Ledger:
         todo = [p for p in params if id(p) not in self.done and id(p) in self.entries]
         if not todo:
             return
+        if self.events:
+            cur = torch.cuda.current_stream()
+            for ev in self.events:
+                cur.wait_event(ev)
+            self.events = []
         if self.sink is None:
             outs, scale = [None] * len(todo), 1.0
         else:

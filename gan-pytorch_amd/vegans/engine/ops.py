@@ -28,7 +28,7 @@ from torch.autograd.function import once_differentiable
 
 from .. import _hip
 from .._hip import ConvGeom, _ptr, _stream, call, workspace
-from . import grads
+from . import grads, streams
 
 CL = torch.channels_last
 
@@ -574,10 +574,13 @@ class BatchNormTrainFn(Function):
         mean = torch.empty(c, dtype=torch.float32, device=x.device)
         invstd = torch.empty(c, dtype=torch.float32, device=x.device)
         ws, nbytes = _bn_ws(m, c, x.device)
-        call("vg_bn_stats", _ptr(x), m, c, c_float(eps), c_float(momentum), _ptr(mean), _ptr(invstd),
-             _ptr(running_mean), _ptr(running_var),
-             ctypes.c_void_p(batches_tracked.data_ptr()) if batches_tracked is not None else None,
-             ctypes.c_void_p(ws.data_ptr()), c_size_t(nbytes), _stream())
+        # the running statistics are updated once per pass, in program order, also when the passes of a sub-step run
+        # on different streams
+        with streams.ordered_write(running_mean):
+            call("vg_bn_stats", _ptr(x), m, c, c_float(eps), c_float(momentum), _ptr(mean), _ptr(invstd),
+                 _ptr(running_mean), _ptr(running_var),
+                 ctypes.c_void_p(batches_tracked.data_ptr()) if batches_tracked is not None else None,
+                 ctypes.c_void_p(ws.data_ptr()), c_size_t(nbytes), _stream())
         y = torch.empty_like(x)
         call("vg_bn_apply", _ptr(x), _ptr(mean), _ptr(invstd), _ptr(gamma), _ptr(beta), _ptr(y), m, c,
              act, c_float(slope), _stream())

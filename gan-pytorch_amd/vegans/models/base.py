@@ -25,7 +25,7 @@ from datetime import datetime
 import numpy as np
 import torch
 
-from ..engine import graph, ops, optim as hip_optim, parallel
+from ..engine import graph, ops, optim as hip_optim, parallel, streams
 from ..utils import utils
 
 
@@ -394,13 +394,17 @@ class AbstractGenerativeModel(ABC):
         accumulation; the seed gradient is a resident device scalar."""
         assert len(self._losses) != 0, "'self._losses' empty when performing '_backward'."
         seed = ops.unit_scalar(self.device)
-        with parallel.open_ledger(self, who):
+        with parallel.open_ledger(self, who) as ledger:
             if who is not None:
                 self._losses[who].backward(gradient=seed, retain_graph=True)
             else:
                 for loss in self._losses.values():
                     if loss.requires_grad:
                         loss.backward(gradient=seed, retain_graph=True)
+            # backward nodes ran on the streams of their forward passes (engine/streams.py); order the launch stream
+            # behind all of them before the ledger adds up what they produced
+            ledger.events = []
+            streams.join(after_backward=True)
 
     def _step(self, who=None, clamp=None):
         names = [who] if who is not None else list(self.optimizers)

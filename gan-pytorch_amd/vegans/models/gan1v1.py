@@ -14,7 +14,7 @@ kernels as constants; no target tensors are materialised and nothing is read bac
 import numpy as np
 import torch
 
-from ..engine import graph, ops
+from ..engine import graph, ops, streams
 from ..utils import utils
 from ..utils.networks import Adversariat, Generator
 from .base import AbstractConditionalGenerativeModel, AbstractGenerativeModel, resolve_device
@@ -58,11 +58,6 @@ class AbstractGAN1v1(AbstractGenerativeModel):
         gen_loss = self.loss_functions["Generator"](fake_predictions, 1)
         self._losses.update({"Generator": gen_loss})
 
-    def _adversariat_terms(self, fake_predictions, real_predictions):
-        adv_loss_fake = self.loss_functions["Adversariat"](fake_predictions, 0)
-        adv_loss_real = self.loss_functions["Adversariat"](real_predictions, 1)
-        return adv_loss_fake, adv_loss_real
-
     def _publish_adversariat(self, adv_loss_fake, adv_loss_real, penalty=None, weight=0.0):
         # 0.5*(fake+real) [+ weight*penalty] and real/fake in one scalar kernel
         adv_loss, ratio = ops.combine(adv_loss_fake, 0.5, adv_loss_real, 0.5, penalty, weight, want_ratio=True)
@@ -76,10 +71,13 @@ class AbstractGAN1v1(AbstractGenerativeModel):
         self._losses["RealFakeRatio"] = ratio
 
     def _calculate_adversariat_loss(self, X_batch, Z_batch):
+        # the fake and the real pass share nothing but read-only weights: the real pass runs on a stream of its own
         fake_images = self._fake_detached(Z_batch)
-        fake_predictions = self.predict(x=fake_images)
-        real_predictions = self.predict(x=X_batch)
-        self._publish_adversariat(*self._adversariat_terms(fake_predictions, real_predictions))
+        with streams.region() as fork:
+            adv_loss_fake = self.loss_functions["Adversariat"](self.predict(x=fake_images), 0)
+            with fork.branch(0):
+                adv_loss_real = self.loss_functions["Adversariat"](self.predict(x=X_batch), 1)
+        self._publish_adversariat(adv_loss_fake, adv_loss_real)
 
 
 # -- loss selectors ---------------------------------------------------------------------------------------------
@@ -195,11 +193,15 @@ class WassersteinGANGP(_PenaltyMixin, _WassersteinMixin, AbstractGAN1v1):
         self.hyperparameters["lmbda_grad"] = lmbda_grad
 
     def _calculate_adversariat_loss(self, X_batch, Z_batch):
+        # three independent critic passes (fake, real, interpolates with their double backward): the launch stream and
+        # two side streams
         fake_images = self._fake_detached(Z_batch)
-        fake_predictions = self.adversariat(fake_images)
-        real_predictions = self.adversariat(X_batch)
-        adv_loss_fake, adv_loss_real = self._adversariat_terms(fake_predictions, real_predictions)
-        adv_loss_grad = self.loss_functions["GP"](X_batch, fake_images)
+        with streams.region() as fork:
+            adv_loss_fake = self.loss_functions["Adversariat"](self.adversariat(fake_images), 0)
+            with fork.branch(0):
+                adv_loss_real = self.loss_functions["Adversariat"](self.adversariat(X_batch), 1)
+            with fork.branch(1):
+                adv_loss_grad = self.loss_functions["GP"](X_batch, fake_images)
         self._publish_adversariat(adv_loss_fake, adv_loss_real, penalty=adv_loss_grad, weight=self.lmbda_grad)
 
 
@@ -238,9 +240,11 @@ class AbstractConditionalGAN1v1(AbstractConditionalGenerativeModel, AbstractGAN1
 
     def _calculate_adversariat_loss(self, X_batch, Z_batch, y_batch):
         fake_images = self._fake_detached(Z_batch, y=y_batch)
-        fake_predictions = self.predict(x=fake_images, y=y_batch)
-        real_predictions = self.predict(x=X_batch, y=y_batch)
-        self._publish_adversariat(*self._adversariat_terms(fake_predictions, real_predictions))
+        with streams.region() as fork:
+            adv_loss_fake = self.loss_functions["Adversariat"](self.predict(x=fake_images, y=y_batch), 0)
+            with fork.branch(0):
+                adv_loss_real = self.loss_functions["Adversariat"](self.predict(x=X_batch, y=y_batch), 1)
+        self._publish_adversariat(adv_loss_fake, adv_loss_real)
 
 
 class ConditionalVanillaGAN(_VanillaMixin, AbstractConditionalGAN1v1):
@@ -282,11 +286,13 @@ class ConditionalWassersteinGANGP(_PenaltyMixin, _WassersteinMixin, AbstractCond
         fake_images = self._fake_detached(Z_batch, y=y_batch)
         fake_concat = self.concatenate(fake_images, y_batch)
         real_concat = self.concatenate(X_batch, y_batch)
-        fake_predictions = self.adversariat(fake_concat)
-        real_predictions = self.adversariat(real_concat)
-        adv_loss_fake, adv_loss_real = self._adversariat_terms(fake_predictions, real_predictions)
-        # the penalty interpolates the label-augmented inputs (ConditionalWassersteinGANGP.py:100-103)
-        adv_loss_grad = self.loss_functions["GP"](real_concat, fake_concat)
+        with streams.region() as fork:
+            adv_loss_fake = self.loss_functions["Adversariat"](self.adversariat(fake_concat), 0)
+            with fork.branch(0):
+                adv_loss_real = self.loss_functions["Adversariat"](self.adversariat(real_concat), 1)
+            with fork.branch(1):
+                # the penalty interpolates the label-augmented inputs (ConditionalWassersteinGANGP.py:100-103)
+                adv_loss_grad = self.loss_functions["GP"](real_concat, fake_concat)
         self._publish_adversariat(adv_loss_fake, adv_loss_real, penalty=adv_loss_grad, weight=self.lmbda_grad)
 
 
