@@ -149,7 +149,7 @@ class GradReducer:
         return self.flat[bi][off:off + p.numel()]
 
     def deposited(self, ledger, p, n_so_far):
-        if graph.capturing() or self.counts is None or self.counts.get(id(p)) != n_so_far:
+        if _cut_for_collectives() or self.counts is None or self.counts.get(id(p)) != n_so_far:
             return
         ledger.flush([p])
         self._completed(p)
@@ -161,7 +161,7 @@ class GradReducer:
         # Buckets are handed to the collective strictly in bucket order: the order in which parameters complete depends
         # on how autograd schedules the backward pass, which may differ between ranks, and ranks that issue their
         # collectives in different orders pair up the wrong buffers.
-        while self.next < len(self.buckets) and self.pending[self.next] == 0:
+        while self.next < len(self.buckets) and self.pending[self.next] == 0 and not _cut_for_collectives():
             self.launched[self.next] = True
             self.works.append(_all_reduce_async(self.flat[self.next]))
             self.next += 1
@@ -173,7 +173,7 @@ class GradReducer:
             if id(p) in seen:
                 self.touched[self.where[id(p)][0]] = True
         self.counts = seen
-        if not graph.capturing():
+        if not _cut_for_collectives():
             # buckets that got gradients but were not launched from `deposited` (first pass, changed graph, parameters
             # without a gradient this time)
             for bi in range(len(self.buckets)):
@@ -186,7 +186,7 @@ class GradReducer:
         if not self.armed:
             return
         self.armed = False
-        if graph.capturing():
+        if _cut_for_collectives():
             flats = [self.flat[bi] for bi in range(len(self.buckets)) if self.touched[bi]]
             if len(flats) == len(self.flat) and len(flats) > 1:
                 flats = [self.whole]          # one collective instead of one per bucket (padding between them is zero)
@@ -203,10 +203,27 @@ def _gloo():
     return dist.get_backend() == "gloo"
 
 
+def _cut_for_collectives():
+    """While an iteration is being captured: whether the capture is cut at every gradient exchange (the collectives then
+    run between two graph launches, as blocking stream-ordered calls) or the collectives are captured with everything
+    else. Captured, a bucket's all-reduce is a branch of the graph on RCCL's stream that starts as soon as the bucket's
+    last gradient exists and runs beside the rest of the backward pass, also in replayed iterations; that needs a
+    communication library that can be stream-captured (RCCL; not gloo, whose collectives run on the host).
+    VEGANS_DP_CAPTURE_COLLECTIVES=1 selects it, the default is the cut."""
+    if not graph.capturing():
+        return False
+    if _gloo():
+        return True
+    return os.environ.get("VEGANS_DP_CAPTURE_COLLECTIVES", "0") != "1"
+
+
 def _all_reduce_async(flat):
-    """Start the sum of one bucket over all ranks; returns a work handle, or None when it already completed. The gloo
-    transport (CPU rehearsals and single-GPU tests; production is RCCL) is fed host copies: its device path runs
-    copies on private streams from helper threads, which proved unreliable next to HIP graph launches."""
+    """Start the sum of one bucket over all ranks; returns a work handle, or None when it already completed.
+
+    gloo (CPU rehearsals and the two-ranks-on-one-GPU test; production is RCCL) is only ever handed HOST tensors: the
+    bucket is copied to the host (which waits for the stream to reach this point), summed there, and copied back in
+    stream order. No gloo helper thread touches the GPU that way, so nothing gloo does can interleave with graph
+    launches on the device, and no device-wide wait is needed around the exchange."""
     if _gloo() and flat.is_cuda:
         host = flat.cpu()
         dist.all_reduce(host, op=dist.ReduceOp.SUM)
@@ -216,13 +233,9 @@ def _all_reduce_async(flat):
 
 
 def _fenced():
-    """Whether the all-reduces between two graph launches are bracketed by device-wide host waits. Always with gloo,
-    whose device path runs copies on private streams from helper threads: next to HIP graph launches on one GPU that
-    deadlocked intermittently. RCCL collectives are ordinary stream-ordered work (the communication stream waits for
-    the launch stream through an event and the launch stream waits back), so nothing is fenced unless
-    VEGANS_DP_FENCE=1 asks for it: a fence drains the GPU three times per iteration and every graph then starts on an
-    idle device (measured with one RCCL rank at 256 rows: see tools/rccl_one_rank_rehearsal.py)."""
-    return _gloo() or os.environ.get("VEGANS_DP_FENCE", "0") == "1"
+    """VEGANS_DP_FENCE=1 brackets the all-reduces between two graph launches by device-wide host waits (a diagnostic: it
+    drains the GPU three times per iteration)."""
+    return os.environ.get("VEGANS_DP_FENCE", "0") == "1"
 
 
 def _all_reduce_now(flats):
@@ -238,6 +251,28 @@ def _all_reduce_now(flats):
             dist.all_reduce(f, op=dist.ReduceOp.SUM)
     if fenced:
         torch.cuda.synchronize()
+
+
+def reduce_logged(model, losses):
+    """Logged losses under data parallelism: every rank holds the mean over ITS rows; the reported value is the mean over
+    the global batch, i.e. the row-weighted sum over ranks - one small all-reduce per logging event. `losses` is a dict
+    name -> 0-d device tensor; returns name -> python float. `RealFakeRatio` is re-formed from the reduced terms."""
+    names = list(losses)
+    stacked = torch.stack([losses[n].detach().reshape(()).float() for n in names])
+    ctx = getattr(model, "_dp", None)
+    if ctx is not None and ctx.world > 1 and _dist_on():
+        stacked = stacked * (ctx.local_rows / float(ctx.global_rows))
+        if _gloo() and stacked.is_cuda:
+            host = stacked.cpu()
+            dist.all_reduce(host, op=dist.ReduceOp.SUM)
+            stacked = host
+        else:
+            dist.all_reduce(stacked, op=dist.ReduceOp.SUM)
+    values = dict(zip(names, stacked.tolist()))
+    if "RealFakeRatio" in values and ctx is not None and ctx.world > 1:
+        fake = values.get("Adversariat_fake")
+        values["RealFakeRatio"] = values["Adversariat_real"] / fake if fake else float("nan")
+    return values
 
 
 def open_ledger(model, who):

@@ -426,8 +426,8 @@ class AbstractGenerativeModel(ABC):
         self._print("Step: {} / {} (Epoch: {} / {}, Batch: {} / {})".format(
             step, max_steps, epoch + 1, max_epochs, batch, max_batches))
         self._print("---" * 20)
-        for name, loss in self._losses.items():
-            self._print("{}: {}".format(name, loss.item()))
+        for name, value in parallel.reduce_logged(self, self._losses).items():
+            self._print("{}: {}".format(name, value))
         self.batch_training_times.append(time.perf_counter() - self.current_timer)
         self.total_training_time = np.sum(self.batch_training_times)
         time_per_batch = np.mean(self.batch_training_times) / print_every
@@ -473,10 +473,8 @@ class AbstractGenerativeModel(ABC):
     def _append_losses(self, mode):
         if not hasattr(self, "logged_losses"):
             self._create_logged_losses()
-        # one device->host transfer per logging event
-        names = list(self._losses)
-        values = torch.stack([self._losses[n].detach().reshape(()) for n in names]).tolist()
-        for name, value in zip(names, values):
+        # one device->host transfer per logging event (under data parallelism: one all-reduce of the row-weighted values)
+        for name, value in parallel.reduce_logged(self, self._losses).items():
             self.logged_losses[mode][name].append(value)
 
     def _create_logged_losses(self):

@@ -321,24 +321,48 @@ class OracleGAN:
                         else:
                             history.append((name, self.sub_step(name, X, Z, y, alpha)))
                 if print_every is not None and step % print_every == 0:
-                    self.all_losses(X, Z, y, draw_alpha())                       # :329-335 (values printed only)
+                    self.all_losses(X, Z, y, draw_alpha(), shards)               # :329-335 (values printed only)
                 if save_losses_every is not None and step % save_losses_every == 0:
                     # the conditional classes log the TRAIN images against the TEST labels
                     # (AbstractConditionalGenerativeModel.py:162)
-                    self._log("Train", self.all_losses(X, Z, test_y if self.conditional else None, draw_alpha()),
+                    self._log("Train", self.all_losses(X, Z, test_y if self.conditional else None, draw_alpha(), shards),
                               X_test is not None)
                     if test_x is not None:
-                        self._log("Test", self.all_losses(test_x, draw_z(len(test_x)), test_y, draw_alpha()), True)
+                        self._log("Test", self.all_losses(test_x, draw_z(len(test_x)), test_y, draw_alpha(), shards), True)
         self._set_mode(False)
         return history
 
-    def all_losses(self, X, Z, y=None, alpha=None):
+    def all_losses(self, X, Z, y=None, alpha=None, shards=1):
         """`calculate_losses(who=None)`: every network's loss on one batch, generator first
-        (AbstractGAN1v1.py:57-64, LRGAN.py:83-93)."""
-        out = {}
-        for who in self.nets:
-            out.update(self.losses(who, X, Z, y, alpha if who == "Adversariat" else None))
-        return {k: float(v.detach()) for k, v in out.items()}
+        (AbstractGAN1v1.py:57-64, LRGAN.py:83-93). `shards` > 1: as nn.DataParallel evaluates it, chunk by chunk with
+        per-chunk BatchNorm statistics, the chunk means weighted by rows / batch (see sub_step_sharded); the buffers
+        keep what the first chunk's pass left."""
+        if shards <= 1:
+            out = {}
+            for who in self.nets:
+                out.update(self.losses(who, X, Z, y, alpha if who == "Adversariat" else None))
+            return {k: float(v.detach()) for k, v in out.items()}
+        rows, start, bounds = len(X), 0, []
+        for piece in torch.chunk(torch.arange(rows), shards):
+            bounds.append((start, start + len(piece)))
+            start += len(piece)
+        totals, first_buffers = {}, None
+        for lo, hi in bounds:
+            part = {}
+            for who in self.nets:
+                part.update(self.losses(who, X[lo:hi], Z[lo:hi], None if y is None else y[lo:hi],
+                                        alpha[lo:hi] if (alpha is not None and who == "Adversariat") else None))
+            for k, v in part.items():
+                totals[k] = totals.get(k, 0.0) + (hi - lo) / float(rows) * float(v.detach())
+            if first_buffers is None:
+                first_buffers = {name: {k: b.detach().clone() for k, b in net.named_buffers()}
+                                 for name, net in self.nets.items()}
+        for name, net in self.nets.items():
+            for k, b in net.named_buffers():
+                b.data.copy_(first_buffers[name][k])
+        if "RealFakeRatio" in totals:
+            totals["RealFakeRatio"] = totals["Adversariat_real"] / totals["Adversariat_fake"]
+        return totals
 
     def _log(self, mode, values, with_test):
         """AbstractGenerativeModel.py:438-453. The "Test" key exists whenever logging happens: `nr_test` is 0, not None,

@@ -108,6 +108,33 @@ for name, net_o in oracle.nets.items():
 print("rank %%d batch-norm data parallel vs two-device oracle: %%d problems" %% (rank, len(problems)))
 assert not problems, "\n".join(problems)
 
+# ---- logged losses under data parallelism: row-weighted means over the global batch, one all-reduce per event ----------
+torch.manual_seed(3); np.random.seed(3)
+Go, Do = bn_nets()
+oracle = OracleGAN("wgangp", Go, Do, (3, 16, 16), (16, 1, 1), optim_kwargs=copy.deepcopy(okw), fixed_noise_size=4)
+np.random.seed(29)
+oracle.fit(Xb[:B * 4], None, epochs=1, batch_size=B, latents=[z.clone() for z in Zs[:4]], shards=world,
+           save_losses_every=2)
+torch.manual_seed(3); np.random.seed(3)
+Gm, Dm = bn_nets()
+with contextlib.redirect_stdout(io.StringIO()):
+    mg = gan.WassersteinGANGP(Gm, Dm, x_dim=(3, 16, 16), z_dim=(16, 1, 1), folder=None, fixed_noise_size=4, ngpu=world,
+                              optim_kwargs=copy.deepcopy(okw))
+zi = iter(Zs[:4])
+mg.sample = lambda n: next(zi)[:n].to("cuda").requires_grad_(True)
+np.random.seed(29)
+with contextlib.redirect_stdout(io.StringIO()):
+    mg.fit(Xb[:B * 4], epochs=1, batch_size=B, print_every=None, save_losses_every=2, enable_tensorboard=False)
+got, want = mg.get_losses()["Train"], oracle.logged_losses["Train"]
+assert set(got) == set(want), (set(got), set(want))
+for k in want:
+    assert len(got[k]) == len(want[k]) == 2, (k, got[k], want[k])
+    if k == "RealFakeRatio":
+        continue
+    for a, b in zip(got[k], want[k]):
+        assert abs(a - b) <= 1e-4 * max(abs(b), 1e-1), (k, a, b)
+print("rank %%d logged losses under data parallel match the two-device oracle" %% rank)
+
 # ---- LSGAN with Adam (device-side step scalars refreshed per replay) through the graph chain -------------------------
 def ls_nets():
     return (cfg.seeded_init(cfg.dcgan_generator(nz=16, ngf=8, nc=3, size=16), 1, 0.08),

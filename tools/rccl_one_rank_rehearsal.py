@@ -83,6 +83,15 @@ def main():
         os.environ["VEGANS_DP_FENCE"] = "0"
         print("graph chain with device-wide waits around the all-reduces: %.2f ms per iteration" % ms_fenced, flush=True)
         compare("graph vs fenced graph", p_graph, p_fenced)
+        if backend == "nccl":
+            # the collectives captured into the iteration's graph (one graph, the all-reduces as branches on RCCL's stream)
+            os.environ["VEGANS_DP_CAPTURE_COLLECTIVES"] = "1"
+            try:
+                ms_cap, p_cap = run(batches, True)
+                print("one graph with the all-reduces captured: %.2f ms per iteration" % ms_cap, flush=True)
+                compare("graph vs graph with captured collectives", p_graph, p_cap)
+            finally:
+                os.environ["VEGANS_DP_CAPTURE_COLLECTIVES"] = "0"
     worst, off = compare("graph vs eager", p_graph, p_eager)
     if dist.is_initialized():
         dist.destroy_process_group()
