@@ -60,15 +60,22 @@ class _Sharded:
         return rows[lo:hi]
 
 
+def needs_workers(model):
+    """ngpu > 1 asked of a process that is not part of a process group: `fit` starts one worker process per GPU itself
+    (engine/spawn.py)."""
+    ngpu = getattr(model, "ngpu", 0) or 0
+    return ngpu > 1 and not (dist.is_available() and dist.is_initialized())
+
+
 def context(model):
     """Decide how `model.fit` shards its batches. ngpu > 1 needs an initialised process group (one rank per GPU)."""
     ngpu = getattr(model, "ngpu", 0) or 0
     if ngpu > 1:
         if not _dist_on():
             raise RuntimeError(
-                "ngpu=%d: multi-GPU training runs one process per GPU. Launch the script with "
-                "`python -m torch.distributed.run --nproc-per-node %d ...` and call "
-                "torch.distributed.init_process_group('nccl') before constructing the model." % (ngpu, ngpu))
+                "ngpu=%d, but this process belongs to a process group of a single rank: launch one rank per GPU "
+                "(`python -m torch.distributed.run --nproc-per-node %d ...`), or leave the process group "
+                "uninitialised and let fit() start the workers itself." % (ngpu, ngpu))
         ctx = _Sharded(dist.get_world_size(), dist.get_rank())
         model._dp = ctx
         for name, net in model.neural_nets.items():

@@ -138,7 +138,7 @@ class AbstractGenerativeModel(ABC):
         nr_batches = utils.number_of_batches(len(X_train), batch_size)
 
         writer_train = writer_test = None
-        if enable_tensorboard:
+        if enable_tensorboard and parallel.is_main():
             writer_cls = _summary_writer_class()
             if writer_cls is not None:
                 writer_train = writer_cls(self.folder + "tensorboard/train/")
@@ -197,10 +197,12 @@ class AbstractGenerativeModel(ABC):
     def _set_up_saver(self, print_every, save_model_every, save_images_every, save_losses_every, nr_batches):
         print_every = _period(print_every, nr_batches)
         if save_model_every is not None:
-            os.mkdir(self.folder + "models/")
+            if parallel.is_main():
+                os.mkdir(self.folder + "models/")
             save_model_every = _period(save_model_every, nr_batches)
         if save_images_every is not None:
-            os.mkdir(self.folder + "images/")
+            if parallel.is_main():
+                os.mkdir(self.folder + "images/")
             save_images_every = _period(save_images_every, nr_batches)
         save_losses_every = _period(save_losses_every, nr_batches)
         self.total_training_time = 0
@@ -287,6 +289,14 @@ class AbstractGenerativeModel(ABC):
         """Train the networks. Arguments as in the reference (AbstractGenerativeModel.py:265-297)."""
         if not getattr(self, "_init_run", False):
             raise ValueError("Run initializer of the AbstractGenerativeModel class is your subclass!")
+        if parallel.needs_workers(self):
+            # ngpu > 1 in a plain single process: one worker process per GPU trains, the result comes back into this
+            # object (the reference fans out inside the process with nn.DataParallel, utils/networks.py:39-41)
+            from ..engine import spawn
+            return spawn.fit_in_workers(self, dict(
+                X_train=X_train, X_test=X_test, epochs=epochs, batch_size=batch_size, steps=steps,
+                print_every=print_every, save_model_every=save_model_every, save_images_every=save_images_every,
+                save_losses_every=save_losses_every, enable_tensorboard=enable_tensorboard))
         nr_batches, writer_train, writer_test, save_periods = self._set_up_training(
             X_train, y_train=None, X_test=X_test, y_test=None, epochs=epochs, batch_size=batch_size, steps=steps,
             print_every=print_every, save_model_every=save_model_every, save_images_every=save_images_every,
@@ -445,6 +455,8 @@ class AbstractGenerativeModel(ABC):
         matplotlib.use("Agg", force=False)
         import matplotlib.pyplot as plt
         images = _as_numpy_nchw(images)
+        if not parallel.is_main():
+            return
         if writer is not None:
             writer.add_images("images", images[:, :3] if images.shape[1] >= 3 else images[:, :1], step)
         self._build_images(images)
@@ -488,7 +500,7 @@ class AbstractGenerativeModel(ABC):
                 self.logged_losses["Test"][name] = []
 
     def _save_losses_plot(self):
-        if hasattr(self, "logged_losses"):
+        if hasattr(self, "logged_losses") and parallel.is_main():
             import matplotlib.pyplot as plt
             utils.plot_losses(self.logged_losses, show=False, share=False)
             plt.savefig(self.folder + "losses.png")
@@ -533,7 +545,8 @@ class AbstractGenerativeModel(ABC):
         """Pickle the whole model object, as the reference does (AbstractGenerativeModel.py:534-546)."""
         if name is None:
             name = "model.torch"
-        torch.save(self, self.folder + name)
+        if parallel.is_main():      # under data parallelism the ranks hold identical models: one writes
+            torch.save(self, self.folder + name)
         self._print("Model saved to {}.".format(self.folder + name))
 
     @staticmethod
@@ -629,6 +642,13 @@ class AbstractConditionalGenerativeModel(AbstractGenerativeModel):
     def fit(self, X_train, y_train, X_test=None, y_test=None, epochs=5, batch_size=32, steps=None, print_every="1e",
             save_model_every=None, save_images_every=None, save_losses_every="1e", enable_tensorboard=True):
         """Train the conditional networks. Arguments as AbstractConditionalGenerativeModel.py:72-108."""
+        if parallel.needs_workers(self):
+            from ..engine import spawn
+            return spawn.fit_in_workers(self, dict(
+                X_train=X_train, y_train=y_train, X_test=X_test, y_test=y_test, epochs=epochs, batch_size=batch_size,
+                steps=steps, print_every=print_every, save_model_every=save_model_every,
+                save_images_every=save_images_every, save_losses_every=save_losses_every,
+                enable_tensorboard=enable_tensorboard))
         nr_batches, writer_train, writer_test, save_periods = self._set_up_training(
             X_train, y_train, X_test=X_test, y_test=y_test, epochs=epochs, batch_size=batch_size, steps=steps,
             print_every=print_every, save_model_every=save_model_every, save_images_every=save_images_every,

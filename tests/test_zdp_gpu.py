@@ -185,3 +185,58 @@ def test_two_rank_data_parallel_matches_single_process(gpu, tmp_path):
     for p, out in zip(procs, outs):
         assert p.returncode == 0, out[-3000:]
         assert "ok" in out
+
+
+def test_ngpu_inside_one_fit_call(gpu):
+    """`ngpu=2` handed to the constructor of a model in a plain single process (no process group): `fit` starts the two
+    workers itself (engine/spawn.py; here both on the one GPU of the box, gloo transport) and writes their result back
+    into the caller's modules, optimizers and model. A BatchNorm-free WGAN-GP must then equal the same fit on the whole
+    batches in this process (the row-weighted shard means are the global mean), consume the random streams identically,
+    and keep the caller's Parameter objects."""
+    import contextlib
+    import io
+
+    import numpy as np
+    import torch
+    from torch import nn
+
+    import bench_configs as cfg
+    import vegans.GAN as gan
+
+    def nets():
+        G = nn.Sequential(nn.ConvTranspose2d(8, 16, 4, 1, 0), nn.ReLU(), nn.ConvTranspose2d(16, 8, 4, 2, 1), nn.ReLU(),
+                          nn.ConvTranspose2d(8, 3, 4, 2, 1), nn.Tanh())
+        D = nn.Sequential(nn.Conv2d(3, 8, 4, 2, 1), nn.LeakyReLU(0.2), nn.Conv2d(8, 16, 4, 2, 1), nn.LeakyReLU(0.2),
+                          nn.Conv2d(16, 1, 4, 1, 0), nn.Flatten(), nn.Identity())
+        return cfg.seeded_init(G, 1, 0.1), cfg.seeded_init(D, 2, 0.1)
+
+    X = cfg.synthetic_images(8 * 5 - 2, (3, 16, 16), seed=3)
+    results = []
+    os.environ["VEGANS_DP_BACKEND"] = "gloo"
+    try:
+        for ngpu in (None, 2):
+            torch.manual_seed(5)
+            np.random.seed(5)
+            G, D = nets()
+            with contextlib.redirect_stdout(io.StringIO()):
+                m = gan.WassersteinGANGP(G, D, x_dim=(3, 16, 16), z_dim=(8, 1, 1), folder=None, fixed_noise_size=2,
+                                         ngpu=ngpu, optim_kwargs={"Generator": {"lr": 1e-3}, "Adversariat": {"lr": 1e-3}})
+                before = [id(p) for p in G.parameters()]
+                m.fit(X, epochs=1, batch_size=8, print_every=None, save_losses_every=2, enable_tensorboard=False)
+            assert [id(p) for p in G.parameters()] == before
+            assert not m.generator.training
+            results.append(([p.detach().cpu().clone() for net in (G, D) for p in net.parameters()], m.get_losses(),
+                            float(torch.rand(1, device="cuda")), float(np.random.random()),
+                            [float(m.optimizers["Adversariat"].state[p]["step"]) for p in D.parameters()]))
+    finally:
+        os.environ.pop("VEGANS_DP_BACKEND", None)
+    (p1, l1, t1, n1, s1), (p2, l2, t2, n2, s2) = results
+    assert t1 == t2 and n1 == n2, "the caller's random streams did not advance as in a single-process fit"
+    assert s1 == s2 == [5.0] * len(s1)
+    worst = max(float((a - b).abs().max() / b.abs().max().clamp_min(1e-3)) for a, b in zip(p2, p1))
+    assert worst < 2e-4, worst
+    assert set(l1["Train"]) == set(l2["Train"])
+    for k in l1["Train"]:
+        if k != "RealFakeRatio":
+            for a, b in zip(l2["Train"][k], l1["Train"][k]):
+                assert abs(a - b) <= 1e-4 * max(abs(b), 1e-1), (k, a, b)
