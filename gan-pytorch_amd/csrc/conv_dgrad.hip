@@ -59,6 +59,8 @@ extern "C" int vg_conv2d_dgrad_prec(const vg_conv_geom* g, const float* gy, cons
     VG_CHECK_LAUNCH("vg_conv2d_dgrad(planes)");
     return VG_OK;
   }
+  if (igemm_set_operands(p, (long long)g->N * g->Ho * g->Wo * g->Co, (long long)g->Co * g->kh * g->kw * g->Ci))
+    return vg_fail(VG_ERR_INVALID, "vg_conv2d_dgrad: the MFMA kernels address operands with 31-bit byte offsets; gy or w is 2 GiB or larger");
   if (igemm_launch<MODE_DGRAD, true>(p, bm, bn, va, vb, grid, (hipStream_t)stream, precision) != 0)
     return vg_fail(VG_ERR_INVALID, "vg_conv2d_dgrad: no kernel variant for bn=%d va=%d vb=%d", bn, va, vb);
   VG_CHECK_LAUNCH("vg_conv2d_dgrad");

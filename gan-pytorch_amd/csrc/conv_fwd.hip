@@ -70,6 +70,8 @@ extern "C" int vg_conv2d_fwd_prec(const vg_conv_geom* g, const float* x, const f
     VG_CHECK_LAUNCH("vg_conv2d_fwd(planes)");
     return VG_OK;
   }
+  if (igemm_set_operands(p, (long long)g->N * g->H * g->W * g->Ci, (long long)g->Co * p.Ktot))
+    return vg_fail(VG_ERR_INVALID, "vg_conv2d_fwd: the MFMA kernels address operands with 31-bit byte offsets; x or w is 2 GiB or larger");
   if (igemm_launch<MODE_FWD, false>(p, bm, bn, va, vb, grid, (hipStream_t)stream, precision) != 0)
     return vg_fail(VG_ERR_INVALID, "vg_conv2d_fwd: no kernel variant for bn=%d va=%d vb=%d", bn, va, vb);
   VG_CHECK_LAUNCH("vg_conv2d_fwd");
@@ -113,6 +115,8 @@ int vg_gemm_kn(const float* A, const float* B, const float* bias, int bias_mod, 
   const int va = (K % 4 == 0 && vg_aligned16(A)) ? 4 : 1;
   const int vb = (Ncols % 4 == 0 && vg_aligned16(B)) ? 4 : 1;
   dim3 grid((unsigned)(p.mtiles * p.ntiles), 1, 1);
+  if (igemm_set_operands(p, (long long)M * K, (long long)K * Ncols))
+    return vg_fail(VG_ERR_INVALID, "vg_gemm_kn: the MFMA kernels address operands with 31-bit byte offsets; an operand is 2 GiB or larger");
   if (igemm_launch<MODE_FWD, true>(p, bm, bn, va, vb, grid, stream, precision) != 0)
     return vg_fail(VG_ERR_INVALID, "vg_gemm_kn: no kernel variant for bn=%d va=%d vb=%d", bn, va, vb);
   VG_CHECK_LAUNCH("vg_gemm_kn");

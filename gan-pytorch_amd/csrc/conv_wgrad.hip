@@ -189,6 +189,8 @@ extern "C" int vg_conv2d_wgrad_partial_prec(const vg_conv_geom* g, const float* 
     VG_CHECK_LAUNCH("vg_conv2d_wgrad(planes)");
     return VG_OK;
   }
+  if (igemm_set_operands(p, (long long)g->N * g->Ho * g->Wo * g->Co, (long long)g->N * g->H * g->W * g->Ci))
+    return vg_fail(VG_ERR_INVALID, "vg_conv2d_wgrad: the MFMA kernels address operands with 31-bit byte offsets; gy or x is 2 GiB or larger");
   if (igemm_launch<MODE_WGRAD, true>(p, pl.bm, pl.bn, va, vb, grid, (hipStream_t)stream, precision) != 0)
     return vg_fail(VG_ERR_INVALID, "vg_conv2d_wgrad: no kernel variant for bn=%d va=%d vb=%d", pl.bn, va, vb);
   VG_CHECK_LAUNCH("vg_conv2d_wgrad");

@@ -36,7 +36,7 @@ enum { PREC_F32 = 0, PREC_BF16 = 1, PREC_SPLIT = 2 };   // PREC_SPLIT is served 
 
 enum { MODE_FWD = 0, MODE_DGRAD = 1, MODE_WGRAD = 2 };
 
-// A predicated-off lane reads these 16 bytes instead of branching around its load.
+// A predicated-off lane of the thin kernels reads these 16 bytes instead of branching around its load.
 static __device__ __attribute__((aligned(16))) float vg_zero_page[4] = {0.f, 0.f, 0.f, 0.f};  // never written
 
 // n / d for 0 <= n < 2^22 and small positive d, with inv = 1.0f / d: exact because (n + 0.5) / d is at least
@@ -59,13 +59,23 @@ struct IgemmParams {
   int fast_div;        // all row indices < 2^22: row -> (image, y, x) decoding may use float reciprocals
   int bias_mod;
   long long slab_stride;  // wgrad: elements per split-K slab
+  unsigned a_bytes, b_bytes;  // sizes of A and B (below 2 GiB each: igemm_set_operands)
 };
+
+// Operand sizes for the kernel's range-checked loads; -1 when an operand cannot be addressed with a 31-bit byte offset.
+static inline int igemm_set_operands(IgemmParams& p, long long a_elems, long long b_elems) {
+  if (a_elems * 4 >= (1LL << 31) || b_elems * 4 >= (1LL << 31)) return -1;
+  p.a_bytes = (unsigned)(a_elems * 4);
+  p.b_bytes = (unsigned)(b_elems * 4);
+  return 0;
+}
 
 #define IGEMM_BK 32
 #define IGEMM_LDK 36
 
 template <int MODE, int BM, int BN, int WAVES_M, bool B_MC, int VA, int VB, int PREC = PREC_F32, int NW = 4>
-__global__ void __launch_bounds__(NW * 64) igemm_kernel(const IgemmParams p) {
+// (eight-wave blocks are meant to run two to a CU, four waves per SIMD: the register allocator is told so)
+__global__ void __launch_bounds__(NW * 64, NW == 8 ? 4 : 1) igemm_kernel(const IgemmParams p) {
   constexpr int NT = NW * 64;      // threads per block
   constexpr int RPT = NT / 8;      // rows one pass of the [row][k] loaders covers (8 threads x 16 bytes span the 32 k)
   constexpr int BK = IGEMM_BK, LDK = IGEMM_LDK;
@@ -144,6 +154,7 @@ __global__ void __launch_bounds__(NW * 64) igemm_kernel(const IgemmParams p) {
   constexpr int RA = BM / RPT;  // rows per thread, [row][k] layout
   constexpr int TPRA = BM / 4, RPA = NT / TPRA, PA = BK / RPA;  // [k][row] layout
   int a_img[A_MC ? 1 : RA], a_h[A_MC ? 1 : RA], a_w[A_MC ? 1 : RA];
+  unsigned a_base[A_MC ? 1 : RA];
   // row index -> (image, y, x): plane = pixels per image, roww = pixels per image row, of the tensor the rows walk
   const bool fast = p.fast_div != 0;
   const int roww = (MODE == MODE_FWD) ? p.Wo : Wc;
@@ -171,6 +182,9 @@ __global__ void __launch_bounds__(NW * 64) igemm_kernel(const IgemmParams p) {
           a_w[i] = jj + base_w;
         }
       }
+      // byte offset of the row's window origin (channel 0 of tap (0,0)); meaningless, and never used, for rows >= M
+      const int roww_in = (MODE == MODE_FWD) ? p.W : p.Wo;
+      a_base[i] = ((unsigned)(a_img[i] + a_h[i] * roww_in + a_w[i]) * (unsigned)((MODE == MODE_FWD) ? p.Ci : p.Co)) * 4u;
     }
   }
 
@@ -245,154 +259,210 @@ __global__ void __launch_bounds__(NW * 64) igemm_kernel(const IgemmParams p) {
   f32x4 rb[B_IS_MC ? PB : RB];
   const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 
-  // Predicated 16-byte load without a branch and without touching the loaded value: an invalid lane reads the
-  // zero page, so a tile's loads are one straight-line sequence and nothing waits on them until the LDS store.
-  auto ld4 = [&](const float* base, size_t off, bool ok) -> f32x4 {
-    const float* ptr = ok ? base + off : vg_zero_page;
-    return *reinterpret_cast<const f32x4*>(ptr);
+  // ---- operand loads: buffer loads with 32-bit byte offsets --------------------------------------------------------
+  // A load that must not happen (row or k outside the operand, a window position in the padding) is given an offset
+  // with the top bit set: that is beyond any operand (both are smaller than 2 GiB), and the hardware returns zeros for
+  // it. So a tile's loads are one straight-line sequence without branches, selects on 64-bit pointers or a dummy page.
+  constexpr unsigned OOB = 0x80000000u;
+  const __amdgpu_buffer_rsrc_t rsrcA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.A), 0, (int)p.a_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrcB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.B), 0, (int)p.b_bytes, 0x00020000);
+  auto ld4 = [&](const __amdgpu_buffer_rsrc_t& rs, unsigned off) -> f32x4 {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)off, 0, 0));
+  };
+  // 4-byte loads of operands that cannot be read as vectors (3-channel images, odd channel counts); elem = element index
+  auto ld1 = [&](const __amdgpu_buffer_rsrc_t& rs, unsigned elem, bool ok) -> float {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (int)(ok ? elem * 4u : OOB), 0, 0));
   };
 
-  // the same for the 4-byte loads of operands that cannot be read as vectors (3-channel images, odd channel counts)
-  auto ld1 = [&](const float* base, size_t off, bool ok) -> float {
-    const float* ptr = ok ? base + off : vg_zero_page;
-    return *ptr;
+  // Fetching a tile is split in two. point_piece(q) works out the offsets of the 16-byte loads of the next tile, a few
+  // loads per call: pure integer arithmetic, issued between the MFMAs of one slice (see k_step), because a wave that
+  // runs through all of a tile's address arithmetic in one stretch feeds the matrix pipe nothing meanwhile, and the waves
+  // of a block reach that stretch together. fetch_tiles() then issues the loads (after the staging registers have been
+  // written to LDS) and steps the k-walk. Operands that need 4-byte loads do all their work in fetch_tiles().
+  constexpr int NPA = VA == 4 ? (A_MC ? PA : RA) : 0, NPB = VB == 4 ? (B_IS_MC ? PB : RB) : 0, NP = NPA + NPB;
+  constexpr int NPIECE = BF ? TM * TN : 4;     // MFMA groups of one slice the address work is spread over
+  unsigned oa[NPA > 0 ? NPA : 1], ob[NPB > 0 ? NPB : 1];
+  // row-invariant part of the fwd/dgrad A offsets of one k-step, set by the first piece
+  int pt_ta = 0, pt_tb = 0;
+  unsigned pt_tap = 0;
+  bool pt_kvalid = false;
+  const unsigned m4ok_mask = (A_MC && m0 + 4 * (tid % TPRA) < p.Co) ? 0u : OOB;   // wgrad A: this thread's 4 columns exist
+  // fwd weights w[co][k], tile [n][k]: byte offset of this thread's rows (k-invariant)
+  unsigned b_rowbase[(!B_IS_MC && VB == 4) ? RB : 1];
+  if constexpr (!B_IS_MC && VB == 4) {
+#pragma unroll
+    for (int i = 0; i < RB; ++i) {
+      const int n = n0 + (tid >> 3) + RPT * i;
+      b_rowbase[i] = n < p.Ncols ? (unsigned)n * (unsigned)Ktot * 4u : OOB;
+    }
+  }
+  const unsigned bn4_mask = bn4 < p.Ncols ? 0u : OOB;
+
+  auto point_a = [&](int i) {
+    if constexpr (NPA > 0) {
+      if constexpr (!A_MC) {
+        const int hi = (MODE == MODE_FWD) ? a_h[i] + pt_ta : a_h[i] - pt_ta;
+        const int wi = (MODE == MODE_FWD) ? a_w[i] + pt_tb : a_w[i] - pt_tb;
+        const unsigned lim_h = (MODE == MODE_FWD) ? p.H : p.Ho, lim_w = (MODE == MODE_FWD) ? p.W : p.Wo;
+        const bool ok = pt_kvalid & ((unsigned)hi < lim_h) & ((unsigned)wi < lim_w);
+        oa[i] = ok ? a_base[i] + pt_tap : OOB;
+      } else {
+        // wgrad A = gy[pixel][co], tile [k][m]
+        const int pix = kpos + krowA(i);
+        const unsigned off = ((unsigned)pix * (unsigned)p.Co + (unsigned)(m0 + 4 * (tid % TPRA))) * 4u;
+        oa[i] = (pix < kend ? off : OOB) | m4ok_mask;
+      }
+    }
+  };
+  auto point_b = [&](int i) {
+    if constexpr (NPB > 0) {
+      if constexpr (!B_IS_MC) {
+        const int k4 = kpos + 4 * (tid & 7);
+        ob[i] = (b_rowbase[i] + (unsigned)k4 * 4u) | (k4 < kend ? 0u : OOB);
+      } else if constexpr (MODE == MODE_FWD) {
+        // plain GEMM operand B[k][n] (row stride Ncols)
+        const int k = kpos + krowB(i);
+        ob[i] = (k < kend ? ((unsigned)k * (unsigned)p.Ncols + (unsigned)bn4) * 4u : OOB) | bn4_mask;
+      } else if constexpr (MODE == MODE_DGRAD) {
+        // weights w[co][kh][kw][ci] read as B[k=(tap,co)][n=ci]
+        const int k = kpos + krowB(i);
+        const int bta = vg_div_small(bk_t[i], inv_ntw), btb = bk_t[i] - bta * ntw;
+        const int kh = cls_h + p.sh * bta, kw = cls_w + p.sw * btb;
+        const unsigned off = ((unsigned)((bk_co[i] * p.KH + kh) * p.KW + kw) * (unsigned)p.Ci + (unsigned)bn4) * 4u;
+        ob[i] = (k < kend ? off : OOB) | bn4_mask;
+      } else {
+        // wgrad B = x window, tile [k=pixel][n=(kh,kw,ci)]
+        const int pix = kpos + krowB(i);
+        const int bpn = vg_div_small(bp_row[i], inv_ho), bpho = bp_row[i] - bpn * p.Ho;
+        const int hi = bpho * p.sh - p.ph + b_ta[0], wi = bp_wo[i] * p.sw - p.pw + b_tb[0];
+        const bool ok = (pix < kend) & ((unsigned)hi < (unsigned)p.H) & ((unsigned)wi < (unsigned)p.W);
+        ob[i] = ok ? ((unsigned)((bpn * p.H + hi) * p.W + wi) * (unsigned)p.Ci + (unsigned)b_ci[0]) * 4u : OOB;
+      }
+    }
+  };
+  auto point_piece = [&](int q) {
+    if constexpr (NPA > 0 && !A_MC) {
+      if (q == 0) {
+        pt_kvalid = kpos + 4 * (tid & 7) < kend;
+        pt_ta = vg_div_small(ak_t, inv_ntw);
+        pt_tb = ak_t - pt_ta * ntw;
+        if constexpr (MODE == MODE_FWD) pt_tap = ((unsigned)(pt_ta * p.W + pt_tb) * (unsigned)p.Ci + (unsigned)ak_c) * 4u;
+        else pt_tap = ((unsigned)ak_c - (unsigned)(pt_ta * p.Wo + pt_tb) * (unsigned)p.Co) * 4u;
+      }
+    }
+#pragma unroll
+    for (int idx = 0; idx < NP; ++idx) {
+      if (idx * NPIECE / (NP > 0 ? NP : 1) == q) {
+        if (idx < NPA) point_a(idx);
+        else point_b(idx - NPA);
+      }
+    }
+  };
+  auto point_tiles = [&]() {
+#pragma unroll
+    for (int q = 0; q < NPIECE; ++q) point_piece(q);
   };
 
-  auto load_tiles = [&]() {
+  auto fetch_tiles = [&]() {
     const int kb = kpos;
     // ---------------- A ----------------
-    if constexpr (!A_MC) {
+    if constexpr (VA == 4) {
+#pragma unroll
+      for (int i = 0; i < NPA; ++i) ra[i] = ld4(rsrcA, oa[i]);
+    } else if constexpr (!A_MC) {
       const int k4 = kb + 4 * (tid & 7);
       const int Cch = (MODE == MODE_FWD) ? p.Ci : p.Co;
-      if constexpr (VA == 4) {
-        const bool kvalid = k4 < kend;
-        const int ak_ta = vg_div_small(ak_t, inv_ntw), ak_tb = ak_t - ak_ta * ntw;
+      int ta[4], tb[4], c[4];
+      bool kv[4];
 #pragma unroll
-        for (int i = 0; i < RA; ++i) {
-          if constexpr (MODE == MODE_FWD) {
-            const int hi = a_h[i] + ak_ta, wi = a_w[i] + ak_tb;
-            const bool ok = kvalid && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
-            ra[i] = ld4(p.A, (size_t)(a_img[i] + hi * p.W + wi) * p.Ci + ak_c, ok);
-          } else {
-            const int ho = a_h[i] - ak_ta, wo = a_w[i] - ak_tb;
-            const bool ok = kvalid && (unsigned)ho < (unsigned)p.Ho && (unsigned)wo < (unsigned)p.Wo;
-            ra[i] = ld4(p.A, (size_t)(a_img[i] + ho * p.Wo + wo) * p.Co + ak_c, ok);
-          }
-        }
-      } else {
-        int ta[4], tb[4], c[4];
-        bool kv[4];
+      for (int e = 0; e < 4; ++e) {
+        const int k = k4 + e;
+        kv[e] = k < kend;
+        const int tap = k / Cch;
+        c[e] = k - tap * Cch;
+        ta[e] = tap / ntw;
+        tb[e] = tap - ta[e] * ntw;
+      }
+#pragma unroll
+      for (int i = 0; i < RA; ++i) {
+        f32x4 v = zero4;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          const int k = k4 + e;
-          kv[e] = k < kend;
-          const int tap = k / Cch;
-          c[e] = k - tap * Cch;
-          ta[e] = tap / ntw;
-          tb[e] = tap - ta[e] * ntw;
-        }
-#pragma unroll
-        for (int i = 0; i < RA; ++i) {
-          f32x4 v = zero4;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            if constexpr (MODE == MODE_FWD) {
-              const int hi = a_h[i] + ta[e], wi = a_w[i] + tb[e];
-              v[e] = ld1(p.A, (size_t)(a_img[i] + hi * p.W + wi) * p.Ci + c[e],
-                         kv[e] && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W);
-            } else {
-              const int ho = a_h[i] - ta[e], wo = a_w[i] - tb[e];
-              v[e] = ld1(p.A, (size_t)(a_img[i] + ho * p.Wo + wo) * p.Co + c[e],
-                         kv[e] && (unsigned)ho < (unsigned)p.Ho && (unsigned)wo < (unsigned)p.Wo);
-            }
+          if constexpr (MODE == MODE_FWD) {
+            const int hi = a_h[i] + ta[e], wi = a_w[i] + tb[e];
+            v[e] = ld1(rsrcA, (unsigned)(a_img[i] + hi * p.W + wi) * (unsigned)p.Ci + (unsigned)c[e],
+                       kv[e] && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W);
+          } else {
+            const int ho = a_h[i] - ta[e], wo = a_w[i] - tb[e];
+            v[e] = ld1(rsrcA, (unsigned)(a_img[i] + ho * p.Wo + wo) * (unsigned)p.Co + (unsigned)c[e],
+                       kv[e] && (unsigned)ho < (unsigned)p.Ho && (unsigned)wo < (unsigned)p.Wo);
           }
-          ra[i] = v;
         }
+        ra[i] = v;
       }
     } else {
-      // wgrad A = gy[pixel][co], tile [k][m]
       const int m4 = m0 + 4 * (tid % TPRA);
 #pragma unroll
       for (int i = 0; i < PA; ++i) {
         const int pix = kb + krowA(i);
-        if constexpr (VA == 4) {
-          ra[i] = ld4(p.A, (size_t)pix * p.Co + m4, pix < kend && m4 < p.Co);
-        } else {
-          f32x4 v;
+        f32x4 v;
 #pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = ld1(p.A, (size_t)pix * p.Co + m4 + e, pix < kend && m4 + e < p.Co);
-          ra[i] = v;
-        }
+        for (int e = 0; e < 4; ++e)
+          v[e] = ld1(rsrcA, (unsigned)pix * (unsigned)p.Co + (unsigned)(m4 + e), pix < kend && m4 + e < p.Co);
+        ra[i] = v;
       }
     }
     // ---------------- B ----------------
-    if constexpr (!B_IS_MC) {
-      // fwd weights w[co][k]: tile [n][k]
+    if constexpr (VB == 4) {
+#pragma unroll
+      for (int i = 0; i < NPB; ++i) rb[i] = ld4(rsrcB, ob[i]);
+    } else if constexpr (!B_IS_MC) {
       const int k4 = kb + 4 * (tid & 7);
 #pragma unroll
       for (int i = 0; i < RB; ++i) {
         const int n = n0 + (tid >> 3) + RPT * i;
-        if constexpr (VB == 4) {
-          rb[i] = ld4(p.B, (size_t)n * Ktot + k4, n < p.Ncols && k4 < kend);
-        } else {
-          f32x4 v;
+        f32x4 v;
 #pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = ld1(p.B, (size_t)n * Ktot + k4 + e, n < p.Ncols && k4 + e < kend);
-          rb[i] = v;
-        }
+        for (int e = 0; e < 4; ++e)
+          v[e] = ld1(rsrcB, (unsigned)n * (unsigned)Ktot + (unsigned)(k4 + e), n < p.Ncols && k4 + e < kend);
+        rb[i] = v;
       }
     } else if constexpr (MODE == MODE_FWD) {
-      // plain GEMM operand B[k][n] (row stride Ncols)
 #pragma unroll
       for (int i = 0; i < PB; ++i) {
         const int k = kb + krowB(i);
-        if constexpr (VB == 4) {
-          rb[i] = ld4(p.B, (size_t)k * p.Ncols + bn4, k < kend && bn4 < p.Ncols);
-        } else {
-          f32x4 v;
+        f32x4 v;
 #pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = ld1(p.B, (size_t)k * p.Ncols + bn4 + e, k < kend && bn4 + e < p.Ncols);
-          rb[i] = v;
-        }
+        for (int e = 0; e < 4; ++e)
+          v[e] = ld1(rsrcB, (unsigned)k * (unsigned)p.Ncols + (unsigned)(bn4 + e), k < kend && bn4 + e < p.Ncols);
+        rb[i] = v;
       }
     } else if constexpr (MODE == MODE_DGRAD) {
-      // weights w[co][kh][kw][ci] read as B[k=(tap,co)][n=ci]
 #pragma unroll
       for (int i = 0; i < PB; ++i) {
         const int k = kb + krowB(i);
         const int bta = vg_div_small(bk_t[i], inv_ntw), btb = bk_t[i] - bta * ntw;
         const int kh = cls_h + p.sh * bta, kw = cls_w + p.sw * btb;
-        const size_t base = ((size_t)(bk_co[i] * p.KH + kh) * p.KW + kw) * p.Ci;
-        if constexpr (VB == 4) {
-          rb[i] = ld4(p.B, base + bn4, k < kend && bn4 < p.Ncols);
-        } else {
-          f32x4 v;
+        const unsigned base = (unsigned)((bk_co[i] * p.KH + kh) * p.KW + kw) * (unsigned)p.Ci;
+        f32x4 v;
 #pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = ld1(p.B, base + bn4 + e, k < kend && bn4 + e < p.Ncols);
-          rb[i] = v;
-        }
+        for (int e = 0; e < 4; ++e) v[e] = ld1(rsrcB, base + (unsigned)(bn4 + e), k < kend && bn4 + e < p.Ncols);
+        rb[i] = v;
       }
     } else {
-      // wgrad B = x window, tile [k=pixel][n=(kh,kw,ci)]
 #pragma unroll
       for (int i = 0; i < PB; ++i) {
         const int pix = kb + krowB(i);
         const int bpn = vg_div_small(bp_row[i], inv_ho), bpho = bp_row[i] - bpn * p.Ho;
         const int hb = bpho * p.sh - p.ph, wb = bp_wo[i] * p.sw - p.pw;
-        if constexpr (VB == 4) {
-          const int hi = hb + b_ta[0], wi = wb + b_tb[0];
-          const bool ok = pix < kend && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
-          rb[i] = ld4(p.B, (size_t)((bpn * p.H + hi) * p.W + wi) * p.Ci + b_ci[0], ok);
-        } else {
-          f32x4 v;
+        f32x4 v;
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const int hi = hb + b_ta[e], wi = wb + b_tb[e];
-            v[e] = ld1(p.B, (size_t)((bpn * p.H + hi) * p.W + wi) * p.Ci + b_ci[e],
-                       pix < kend && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W);
-          }
-          rb[i] = v;
+        for (int e = 0; e < 4; ++e) {
+          const int hi = hb + b_ta[e], wi = wb + b_tb[e];
+          v[e] = ld1(rsrcB, (unsigned)((bpn * p.H + hi) * p.W + wi) * (unsigned)p.Ci + (unsigned)b_ci[e],
+                     pix < kend && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W);
         }
+        rb[i] = v;
       }
     }
     // ---------------- advance the k-walk by one tile (branch-free) ----------------
@@ -545,50 +615,66 @@ __global__ void __launch_bounds__(NW * 64) igemm_kernel(const IgemmParams p) {
       }
     }
   };
-  auto mma_frags = [&](const Frag (&af)[TM], const Frag (&bf)[TN]) {
+  // MFMAs of one slice, in NPIECE groups (f32: the four k sub-steps; bf16: one 32x32 tile each)
+  auto mma_piece = [&](const Frag (&af)[TM], const Frag (&bf)[TN], int q) {
     if constexpr (!BF) {
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int mi = 0; mi < TM; ++mi)
-#pragma unroll
-          for (int ni = 0; ni < TN; ++ni)
-            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mi][j], bf[ni][j], acc[mi][ni], 0, 0, 0);
-    } else {
 #pragma unroll
       for (int mi = 0; mi < TM; ++mi)
 #pragma unroll
         for (int ni = 0; ni < TN; ++ni)
-          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mi], bf[ni], acc[mi][ni], 0, 0, 0);
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mi][q], bf[ni][q], acc[mi][ni], 0, 0, 0);
+    } else {
+      const int mi = q / TN, ni = q % TN;
+      acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mi], bf[ni], acc[mi][ni], 0, 0, 0);
+    }
+  };
+  auto mma_frags = [&](const Frag (&af)[TM], const Frag (&bf)[TN]) {
+#pragma unroll
+    for (int q = 0; q < NPIECE; ++q) mma_piece(af, bf, q);
+  };
+  // the same with the address arithmetic of the next tile's loads issued between the groups: an MFMA occupies the
+  // matrix pipe for 16 passes, during which the wave can issue that much other work without the pipe running dry
+  auto mma_frags_pointing = [&](const Frag (&af)[TM], const Frag (&bf)[TN]) {
+#pragma unroll
+    for (int q = 0; q < NPIECE; ++q) {
+      point_piece(q);
+      mma_piece(af, bf, q);
+      __builtin_amdgcn_sched_barrier(0);
     }
   };
 
   Frag afx[TM], bfx[TN], afy[TM], bfy[TN];
 
-  // One k-step on buffer `buf`. On entry afx/bfx hold slice 0 of that buffer and the staging registers hold tile
-  // kt+1, whose global loads were issued a whole k-step ago. Mid-step that tile is written to the other buffer (last
-  // read one k-step ago, behind a barrier) and the loads of tile kt+2 are issued into the freed registers. After the
-  // barrier the first slice of the next buffer is fetched under the MFMAs of the last slice.
-  auto k_step = [&](int kt, int buf) {
+  // One k-step on buffer `buf`, without a branch: every k-step stages "the tile after next" even when there is none
+  // (its loads are predicated off by k >= kend and read the zero page; the LDS buffer they are written to is not read
+  // again), so the whole step is one scheduling region per barrier interval. On entry afx/bfx hold slice 0 of `buf` and
+  // the staging registers hold tile kt+1, whose global loads were issued most of a k-step ago. The addresses of tile
+  // kt+2 are worked out under the MFMAs of one slice; then tile kt+1 is written to the other buffer (last read one
+  // k-step ago, behind a barrier) and the loads of tile kt+2 are issued into the freed registers. After the barrier
+  // the first slice of the next buffer is fetched under the MFMAs of the last slice.
+  auto k_step = [&](int buf) {
     const float* As = smem + buf * BUF;
     const float* Bs = As + A_FLOATS;
     load_frags(As, Bs, 1, afy, bfy);
     __builtin_amdgcn_sched_barrier(0);
-    mma_frags(afx, bfx);
-    if constexpr (!BF) {
+    if constexpr (BF) {
+      mma_frags_pointing(afx, bfx);
+    } else {
+      mma_frags(afx, bfx);
       load_frags(As, Bs, 2, afx, bfx);
       __builtin_amdgcn_sched_barrier(0);
-      mma_frags(afy, bfy);
+      mma_frags_pointing(afy, bfy);
     }
-    if (kt + 1 < nk) store_tiles(buf ^ 1);
-    if (kt + 2 < nk) load_tiles();
+    store_tiles(buf ^ 1);
+    __builtin_amdgcn_sched_barrier(0);   // the loads reuse the staging registers: hoisted above the LDS writes they would need a second set
+    fetch_tiles();
     if constexpr (!BF) {
       load_frags(As, Bs, 3, afy, bfy);
       __builtin_amdgcn_sched_barrier(0);
       mma_frags(afx, bfx);
     }
     __syncthreads();
-    if (kt + 1 < nk) {
+    {
       const float* An = smem + (buf ^ 1) * BUF;
       load_frags(An, An + A_FLOATS, 0, afx, bfx);
     }
@@ -597,19 +683,21 @@ __global__ void __launch_bounds__(NW * 64) igemm_kernel(const IgemmParams p) {
   };
 
   if (nk > 0) {
-    load_tiles();
+    point_tiles();
+    fetch_tiles();
     store_tiles(0);
-    if (nk > 1) load_tiles();
+    point_tiles();
+    fetch_tiles();
   }
   __syncthreads();
   if (nk > 0) load_frags(smem, smem + A_FLOATS, 0, afx, bfx);
 
   int kt = 0;
   for (; kt + 1 < nk; kt += 2) {
-    k_step(kt, 0);
-    k_step(kt + 1, 1);
+    k_step(0);
+    k_step(1);
   }
-  if (kt < nk) k_step(kt, 0);
+  if (kt < nk) k_step(0);
 
   // ---- epilogue: lane holds column (lane&31) and rows (e&3)+8*(e>>2)+4*(lane>>5) of each 32x32 tile ----
   float* outp = p.out;

@@ -10,6 +10,9 @@ export TMPDIR=/tmp
 timeout -k 10 400 python bench.py --steps 50 --warmup 10 > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err
 cd /tmp
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_stats -o ${TAG} -- python $ROOT/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-bf16-extra > $OUT/${TAG}_stats.log 2>&1
+# the same trace with the critic passes on one stream: per-kernel durations free of overlap with other streams' kernels
+# (what the benchmark's event-timed roofline entry measures)
+VEGANS_HIP_STREAMS=0 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_stats1 -o ${TAG}s -- python $ROOT/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-bf16-extra > $OUT/${TAG}_stats1.log 2>&1
 export VEGANS_HIP_GRAPH=0
 export VEGANS_HIP_STREAMS=0
 PMC_CMD="python $ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-kernel-timing --no-bf16-extra --allow-eager"
