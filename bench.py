@@ -235,29 +235,26 @@ def main():
                     "note": "tensors stay f32 in HBM in this mode (operands are rounded to bf16 planes ahead of the "
                             "contraction), so it is bound by operand traffic, not by the matrix cores"}
 
-    # Per-kernel durations for the roofline entry. Kernels inside a replayed graph cannot be bracketed one by one, so
-    # the same iterations run again eagerly with a start/stop event pair around every convolution launch, on the
-    # launch stream. Each iteration is queued behind a GPU-side spin of about one iteration's length, so the kernels
-    # find their successors already enqueued and no host latency leaks into the event intervals.
+    # Per-kernel durations for the roofline entry. Kernels inside a replayed graph cannot be timed one by one, so
+    # the same iterations run again eagerly with a start/stop event pair attached to every convolution launch, on the
+    # launch stream. Each instrumented iteration is queued behind a replayed (untimed) one: the host enqueues the eager
+    # launches while the GPU works through the replay, so the kernels find their successors already enqueued and the
+    # chip in the state the timed region keeps it in. (Behind an idle stretch or a spin kernel the same kernels run
+    # about a tenth slower for some ten milliseconds: the trace of such a run shows it per iteration.)
     timer = None
     if not args.no_kernel_timing:
-        spin_cycles = 1 << 22
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        torch.cuda._sleep(spin_cycles)
-        e1.record()
-        torch.cuda.synchronize()
-        spin_cycles = int(spin_cycles * max(1.5e3 * elapsed / args.steps, 20.0) / max(e0.elapsed_time(e1), 1e-3))
         timer = ops.ConvTimer()
-        ops.conv_timer = timer
-        # one stream here: an event pair brackets ONE kernel's own duration only while nothing else runs beside it
+        # one stream here: a kernel's begin-to-end time is its own cost only while nothing else runs beside it
         # (the timed regions above run the critic's independent passes on separate streams)
         streams_were = streams.set_enabled(False)
-        for i in range(ROOFLINE_STEPS):
-            torch.cuda._sleep(spin_cycles)
+        for i in range(SETUP_STEPS):                # single-stream iterations are a different program: own graph
             step(i)
+        for i in range(ROOFLINE_STEPS):
+            step(2 * i)                             # replayed
+            ops.conv_timer = timer
+            step(2 * i + 1)                         # eager, instrumented
+            ops.conv_timer = None
         streams.set_enabled(streams_were)
-        ops.conv_timer = None
         fence()
     if world > 1:
         t = torch.tensor([elapsed, resident_elapsed], device="cuda", dtype=torch.float64)
@@ -297,7 +294,8 @@ def main():
                                   "(profiles/*_pmc_summary.json: FETCH_SIZE and WRITE_SIZE runs of this benchmark)",
                 "launches": n, "avg_launch_us": round(1e3 * ms / n, 2),
                 "ms_per_step": round(ms / ROOFLINE_STEPS, 3),
-                "timed": "HIP events around each launch, %d eager single-stream iterations after the timed region "
+                "timed": "HIP events attached to each launch's dispatch (kernel begin to kernel end), %d eager "
+                         "single-stream iterations after the timed region, each queued behind a replayed iteration "
                          "(the timed region replays a HIP graph)" % ROOFLINE_STEPS,
             }
             out["conv_kernels"] = {"ms_per_step": round(all_ms / ROOFLINE_STEPS, 3),

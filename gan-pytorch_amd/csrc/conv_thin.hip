@@ -692,7 +692,7 @@ int try_fwd_stem(const vg_conv_geom* g, const float* x, const float* w, const fl
   bool done = false;
 #define STEM_FWD(CI_, KK_, S_)                                                                                          \
   if (!done && g->Ci == CI_ && g->kh == KK_ && g->sh == S_) {                                                          \
-    hipLaunchKernelGGL((stem_fwd_kernel<CI_, KK_, S_>), grid, dim3(256), 0, st, x, w, bias, y, g->H, g->W, g->Co, g->Ho, \
+    vg_launch_timed(stem_fwd_kernel<CI_, KK_, S_>, grid, dim3(256), 0, st, x, w, bias, y, g->H, g->W, g->Co, g->Ho, \
                        g->Wo, g->ph, g->pw, tiles_w, tiles_h, (int)blocks, act, slope);                               \
     done = true;                                                                                                       \
   }
@@ -721,7 +721,7 @@ int vg_try_wgrad_stem(const vg_conv_geom* g, const float* gy, const float* x, fl
   bool done = false;
 #define STEM_WGRAD(CI_, KK_, S_)                                                                                       \
   if (!done && g->Ci == CI_ && g->kh == KK_ && g->sh == S_) {                                                          \
-    hipLaunchKernelGGL((stem_wgrad_kernel<CI_, KK_, S_>), grid, dim3(256), 0, st, gy, x, slabs, g->H, g->W, g->Co,      \
+    vg_launch_timed(stem_wgrad_kernel<CI_, KK_, S_>, grid, dim3(256), 0, st, gy, x, slabs, g->H, g->W, g->Co,      \
                        g->Ho, g->Wo, g->ph, g->pw, tiles_w, tiles_h, (int)tiles);                                      \
     done = true;                                                                                                       \
   }
@@ -750,10 +750,10 @@ int vg_try_fwd_thin(const vg_conv_geom* g, const float* x, const float* w, const
 #define THIN_FWD(CO_)                                                                                                  \
   if (g->Co == CO_) {                                                                                                  \
     if (wide)                                                                                                          \
-      hipLaunchKernelGGL((fwd_thin_kernel<CO_, 256>), grid, dim3(256), 0, st, x, w, bias, y, g->H, g->W, g->Ci, g->kw,  \
+      vg_launch_timed(fwd_thin_kernel<CO_, 256>, grid, dim3(256), 0, st, x, w, bias, y, g->H, g->W, g->Ci, g->kw,  \
                          g->Ho, g->Wo, g->sh, g->sw, g->ph, g->pw, M, K);                                             \
     else                                                                                                               \
-      hipLaunchKernelGGL((fwd_thin_kernel<CO_, 64>), grid, dim3(256), 0, st, x, w, bias, y, g->H, g->W, g->Ci, g->kw,   \
+      vg_launch_timed(fwd_thin_kernel<CO_, 64>, grid, dim3(256), 0, st, x, w, bias, y, g->H, g->W, g->Ci, g->kw,   \
                          g->Ho, g->Wo, g->sh, g->sw, g->ph, g->pw, M, K);                                             \
   }
   THIN_FWD(1) THIN_FWD(2) THIN_FWD(3) THIN_FWD(4)
@@ -815,7 +815,7 @@ static int try_dgrad_scatter(const vg_conv_geom* g, const float* gy, const float
   if (grid > 0x7fffffffLL) return 0;
 #define THIN_SCATTER(CI_, TAPS_)                                                                                        \
   if (g->Ci == CI_ && taps == TAPS_)                                                                                    \
-    hipLaunchKernelGGL((dgrad_scatter_kernel<CI_, TAPS_>), dim3((unsigned)grid), dim3(256), 0, st, gy, w, bias, gx,      \
+    vg_launch_timed(dgrad_scatter_kernel<CI_, TAPS_>, dim3((unsigned)grid), dim3(256), 0, st, gy, w, bias, gx,      \
                        g->H, g->W, g->Co, g->kh, g->kw, g->Ho, g->Wo, g->sh, g->sw, g->ph, g->pw, best_rw, bt_h, bt_w,  \
                        bs_h, bs_w, bo_h, bo_w);
   THIN_SCATTER(1, 9) THIN_SCATTER(2, 9) THIN_SCATTER(3, 9) THIN_SCATTER(4, 9)
@@ -840,7 +840,7 @@ int vg_try_dgrad_thin(const vg_conv_geom* g, const float* gy, const float* w, co
   dim3 grid((unsigned)(g->N * itiles * jtiles), 1, (unsigned)(g->sh * g->sw));
 #define THIN_DGRAD(CI_)                                                                                                 \
   if (g->Ci == CI_)                                                                                                     \
-    hipLaunchKernelGGL((dgrad_thin_kernel<CI_>), grid, dim3(256), lds, st, gy, w, bias, gx, g->H, g->W, g->Co, g->kh,    \
+    vg_launch_timed(dgrad_thin_kernel<CI_>, grid, dim3(256), lds, st, gy, w, bias, gx, g->H, g->W, g->Co, g->kh,    \
                        g->kw, g->Ho, g->Wo, g->sh, g->sw, g->ph, g->pw, cc, itiles, jtiles);
   THIN_DGRAD(1) THIN_DGRAD(2) THIN_DGRAD(3) THIN_DGRAD(4)
 #undef THIN_DGRAD

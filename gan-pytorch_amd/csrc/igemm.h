@@ -771,20 +771,20 @@ static inline int igemm_launch(const IgemmParams& p, int bm, int bn, int va, int
   if (prec == PREC_SPLIT) prec = PREC_F32;   // shapes the plane GEMM does not serve
 #define IGEMM_CASE_P(BM_, BN_, WM_, VA_, VB_, P_)                                                          \
   if (bm == BM_ && bn == BN_ && va == VA_ && vb == VB_) {                                                  \
-    hipLaunchKernelGGL((igemm_kernel<MODE, BM_, BN_, WM_, B_MC, VA_, VB_, P_>), grid, dim3(256), 0, st, p); \
+    vg_launch_timed(igemm_kernel<MODE, BM_, BN_, WM_, B_MC, VA_, VB_, P_>, grid, dim3(256), 0, st, p); \
     return 0;                                                                                              \
   }
   // f32, 16-byte-vector operands: eight waves per block on the three large tiles (half the accumulators per wave, so
   // two blocks bring four waves to every SIMD instead of two; measured +2..10 % on the DCGAN layers)
   if (igemm_waves(bm, bn, va, vb, prec) == 8) {
-    if (bm == 128 && bn == 128) hipLaunchKernelGGL((igemm_kernel<MODE, 128, 128, 2, B_MC, 4, 4, PREC_F32, 8>), grid, dim3(512), 0, st, p);
-    else if (bm == 128) hipLaunchKernelGGL((igemm_kernel<MODE, 128, 64, 4, B_MC, 4, 4, PREC_F32, 8>), grid, dim3(512), 0, st, p);
-    else hipLaunchKernelGGL((igemm_kernel<MODE, 64, 128, 2, B_MC, 4, 4, PREC_F32, 8>), grid, dim3(512), 0, st, p);
+    if (bm == 128 && bn == 128) vg_launch_timed(igemm_kernel<MODE, 128, 128, 2, B_MC, 4, 4, PREC_F32, 8>, grid, dim3(512), 0, st, p);
+    else if (bm == 128) vg_launch_timed(igemm_kernel<MODE, 128, 64, 4, B_MC, 4, 4, PREC_F32, 8>, grid, dim3(512), 0, st, p);
+    else vg_launch_timed(igemm_kernel<MODE, 64, 128, 2, B_MC, 4, 4, PREC_F32, 8>, grid, dim3(512), 0, st, p);
     return 0;
   }
   if (prec == PREC_BF16 && va == 4 && vb == 4 && bm == 128 && bn == 128) {   // eight waves here too (the other tiles
     // would leave a thread with a single row of a packed [k][row] pair)
-    hipLaunchKernelGGL((igemm_kernel<MODE, 128, 128, 2, B_MC, 4, 4, PREC_BF16, 8>), grid, dim3(512), 0, st, p);
+    vg_launch_timed(igemm_kernel<MODE, 128, 128, 2, B_MC, 4, 4, PREC_BF16, 8>, grid, dim3(512), 0, st, p);
     return 0;
   }
   if (prec == PREC_BF16 && va == 4 && vb == 4) {

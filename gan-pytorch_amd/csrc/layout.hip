@@ -20,6 +20,23 @@ int vg_fail(int code, const char* fmt, ...) {
 extern "C" const char* vg_last_error(void) { return vg_error_buffer(); }
 extern "C" int vg_abi_version(void) { return 1; }
 
+VgLaunchTiming* vg_launch_timing() {
+  static thread_local VgLaunchTiming slot = {nullptr, nullptr};
+  return &slot;
+}
+
+extern "C" int vg_time_next_conv(void* start_event, void* stop_event) {
+  VgLaunchTiming* t = vg_launch_timing();
+  t->start = (hipEvent_t)start_event;
+  t->stop = (hipEvent_t)stop_event;
+  return VG_OK;
+}
+
+extern "C" int vg_time_pending(void) {
+  const VgLaunchTiming* t = vg_launch_timing();
+  return (t->start || t->stop) ? 1 : 0;
+}
+
 namespace {
 
 // Per image: src [R][S] -> dst [S][R] through a 32x33 LDS tile (coalesced on both sides).

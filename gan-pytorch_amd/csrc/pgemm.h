@@ -495,10 +495,10 @@ __global__ void __launch_bounds__(NW * 64) pgemm_kernel(const PgemmParams pp) {
 template <int MODE, int NP>
 static inline int pgemm_launch(const PgemmParams& pp, int bm, int bn, dim3 grid, hipStream_t st) {
   constexpr int BK = NP == 1 ? 64 : 32;     // a single plane leaves room for 64-deep tiles: half the barriers per flop
-  if (bm == 128 && bn == 128) hipLaunchKernelGGL((pgemm_kernel<MODE, 128, 128, 2, NP, 8, BK>), grid, dim3(512), 0, st, pp);
-  else if (bm == 128 && bn == 64) hipLaunchKernelGGL((pgemm_kernel<MODE, 128, 64, 4, NP, 8, BK>), grid, dim3(512), 0, st, pp);
-  else if (bm == 64 && bn == 128) hipLaunchKernelGGL((pgemm_kernel<MODE, 64, 128, 2, NP, 8, BK>), grid, dim3(512), 0, st, pp);
-  else if (bm == 64 && bn == 64) hipLaunchKernelGGL((pgemm_kernel<MODE, 64, 64, 2, NP, 4, BK>), grid, dim3(256), 0, st, pp);
+  if (bm == 128 && bn == 128) vg_launch_timed(pgemm_kernel<MODE, 128, 128, 2, NP, 8, BK>, grid, dim3(512), 0, st, pp);
+  else if (bm == 128 && bn == 64) vg_launch_timed(pgemm_kernel<MODE, 128, 64, 4, NP, 8, BK>, grid, dim3(512), 0, st, pp);
+  else if (bm == 64 && bn == 128) vg_launch_timed(pgemm_kernel<MODE, 64, 128, 2, NP, 8, BK>, grid, dim3(512), 0, st, pp);
+  else if (bm == 64 && bn == 64) vg_launch_timed(pgemm_kernel<MODE, 64, 64, 2, NP, 4, BK>, grid, dim3(256), 0, st, pp);
   else return -1;
   return 0;
 }

@@ -1,6 +1,7 @@
 // Internal helpers shared by the gfx950 kernel translation units of libvegans_hip.so.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdarg.h>
 #include <stdio.h>
 #include "../../include/vegans_hip.h"
@@ -51,4 +52,23 @@ __device__ __forceinline__ float vg_block_sum_256(float v, float* red) {
   float r = 0.f;
   if (threadIdx.x == 0) r = (red[0] + red[1]) + (red[2] + red[3]);
   return r;
+}
+
+// One-shot kernel timing (vg_time_next_conv): when a pair of events is pending on this thread, the next contraction
+// kernel is launched with them, and they then hold the begin and end of that kernel's execution on the device (the
+// dispatch's own timestamps, not the moments a marker before and after it drained from the queue).
+struct VgLaunchTiming {
+  hipEvent_t start, stop;
+};
+VgLaunchTiming* vg_launch_timing();   // thread-local slot
+
+template <class K, class... Args>
+static inline void vg_launch_timed(K kernel, dim3 grid, dim3 block, unsigned lds, hipStream_t st, Args... args) {
+  VgLaunchTiming* t = vg_launch_timing();
+  if (t->start || t->stop) {
+    hipExtLaunchKernelGGL(kernel, grid, block, lds, st, t->start, t->stop, 0, args...);
+    t->start = t->stop = nullptr;
+  } else {
+    hipLaunchKernelGGL(kernel, grid, block, lds, st, args...);
+  }
 }

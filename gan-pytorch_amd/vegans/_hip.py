@@ -48,6 +48,8 @@ _G = POINTER(ConvGeom)
 SIGNATURES = {
     "vg_last_error": (ctypes.c_char_p, []),
     "vg_abi_version": (c_int, []),
+    "vg_time_next_conv": (c_int, [c_void_p, c_void_p]),
+    "vg_time_pending": (c_int, []),
     "vg_conv2d_fwd": (c_int, [_G, _P, _P, _P, _P, _P]),
     "vg_conv2d_dgrad": (c_int, [_G, _P, _P, _P, _P, _P]),
     "vg_conv2d_wgrad_workspace_bytes": (c_size_t, [_G]),

@@ -157,25 +157,44 @@ def conv_variant(mode, g):
 
 
 class ConvTimer:
-    """Optional event timing of the convolution kernels (installed by the benchmark): start/stop events are
-    recorded on the stream the kernel is launched on; durations are read after the timed region. With `only` set,
-    just the launches of that kernel variant are bracketed (two event records per launch perturb the stream, so the
-    benchmark's timed region instruments one kernel, not all of them)."""
+    """Optional timing of the convolution kernels (installed by the benchmark). Every launch gets a pair of events that
+    the library hands to the kernel dispatch itself (vg_time_next_conv): they hold the begin and end of that kernel's
+    execution, not the moments at which markers queued around it were reached, which would add the dispatch latency
+    of the kernel to every interval. Durations are read after the timed region. With `only` set, just the launches of
+    that kernel variant are timed. The events are made (and recorded once, which is what creates them) ahead of the
+    timed passes, `capacity` pairs at a time, so the passes themselves put nothing extra on the stream."""
 
-    def __init__(self, only=None):
+    def __init__(self, only=None, capacity=1024):
         self.only = only
         self.records = []   # (variant, geometry, start_event, stop_event, mode)
+        self.untimed = 0    # launches whose kernel does not take the events (none today)
+        self.pool = []
+        self.capacity = capacity
+        self._grow()
+
+    def _grow(self):
+        for _ in range(self.capacity):
+            pair = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            pair[0].record()
+            pair[1].record()
+            self.pool.append(pair)
 
     def launch(self, mode, g, fn):
         name = conv_variant(mode, g)
         if self.only is not None and name != self.only:
             fn()
             return
-        start = torch.cuda.Event(enable_timing=True)
-        stop = torch.cuda.Event(enable_timing=True)
-        start.record()
-        fn()
-        stop.record()
+        if not self.pool:
+            self._grow()
+        start, stop = self.pool.pop()
+        call("vg_time_next_conv", ctypes.c_void_p(start.cuda_event), ctypes.c_void_p(stop.cuda_event))
+        try:
+            fn()
+        finally:
+            if _hip.load().vg_time_pending():
+                call("vg_time_next_conv", None, None)
+                self.untimed += 1
+                return
         self.records.append((name, g, start, stop, mode))
 
     def summary(self):

@@ -94,6 +94,14 @@ int vg_conv2d_wgrad_reduce(const vg_conv_geom* g, float* gw, const void* workspa
  * device looks up the array's device address (hipGetSymbolAddress): make it outside a stream capture. */
 int vg_conv2d_wgrad_noalloc(const vg_conv_geom* g, const float* gy, const float* x, float* gw, void* stream);
 
+/* Measurement aid, no counterpart in the reference: the next vg_conv2d_* call made by this thread launches its
+ * contraction kernel (not its helper kernels: operand conversion, slab sum) with these two hipEvent_t, created by the
+ * caller with timing enabled; after the stream has drained, hipEventElapsedTime(start, stop) is that one kernel's own
+ * execution time on the device. One-shot. vg_time_pending() tells whether a pair set earlier is still waiting for a
+ * kernel (1) or was used (0), and vg_time_next_conv(NULL, NULL) withdraws it. Not for use under stream capture. */
+int vg_time_next_conv(void* start_event, void* stop_event);
+int vg_time_pending(void);
+
 /* The same three contractions with a choice of multiplier precision (the north-star configuration names a bf16 mode
  * next to fp32): VG_PREC_F32 = exact f32 products (what the un-suffixed entry points do); VG_PREC_BF16 = operands
  * rounded to bf16 (nearest even) on their way into the matrix cores, f32 accumulation, f32 tensors in memory;
