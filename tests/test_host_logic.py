@@ -49,6 +49,23 @@ def test_argument_errors_come_back_as_error_codes_not_crashes():
     assert lib.vg_reduce_workspace_bytes(10) == 4
 
 
+def test_operands_of_two_gib_are_refused_before_any_launch():
+    """The MFMA kernels address their operands with 31-bit byte offsets; a larger operand must come back as an error
+    (checked on the host, ahead of the launch: the dummy pointers are never dereferenced)."""
+    from vegans import _hip
+    lib = _hip.load()
+    g = _hip.ConvGeom(4096, 64, 64, 64, 64, 3, 3, 64, 64, 1, 1, 1, 1)      # x and y: 2^30 elements = 4 GiB each
+    dummy = ctypes.c_void_p(256)
+    assert lib.vg_conv2d_fwd(ctypes.byref(g), dummy, dummy, None, dummy, None) == -1
+    assert b"31-bit byte offsets" in lib.vg_last_error()
+    assert lib.vg_conv2d_dgrad(ctypes.byref(g), dummy, dummy, None, dummy, None) == -1
+    assert b"31-bit byte offsets" in lib.vg_last_error()
+    # the timing slot is per thread and starts empty; setting and withdrawing a pair launches nothing
+    assert lib.vg_time_pending() == 0
+    assert lib.vg_time_next_conv(dummy, dummy) == 0 and lib.vg_time_pending() == 1
+    assert lib.vg_time_next_conv(None, None) == 0 and lib.vg_time_pending() == 0
+
+
 def test_ops_refuse_cpu_tensors():
     from vegans import _hip
     from vegans.engine import ops

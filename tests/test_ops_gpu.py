@@ -712,3 +712,37 @@ def test_clamp_reaches_parameters_without_gradient(gpu):
     assert got[:3].tolist() == [float(np.float32(0.01)), float(np.float32(-0.01)), float(np.float32(0.005))]
     assert torch.isnan(got[3])
     assert float(used.detach().abs().max()) == float(np.float32(0.01))
+
+
+@pytest.mark.gpu
+def test_kernel_timing_events_hold_the_kernels_own_duration(gpu):
+    """vg_time_next_conv hands a pair of events to the next contraction launch: the pair is consumed by exactly one kernel
+    (MFMA tile, stem and thin kernels alike), results are unchanged, and the interval is positive and not longer than
+    the same launch bracketed by markers on the stream."""
+    from vegans import _hip
+    from vegans.engine import ops
+    lib = _hip.load()
+    torch.manual_seed(5)
+    for shape in ((32, 16, 16, 64, 128, 4, 2, 1), (16, 32, 32, 3, 64, 4, 2, 1), (16, 4, 4, 512, 1, 4, 1, 0)):
+        N, H, W, Ci, Co, k, s, p = shape
+        g = ops.Geom(N, H, W, Ci, Co, k, k, s, s, p, p)
+        x = torch.randn(N, Ci, H, W, device="cuda").contiguous(memory_format=torch.channels_last)
+        w = (torch.randn(Co, Ci, k, k, device="cuda") * 0.05).contiguous(memory_format=torch.channels_last)
+        want = ops.raw_conv_fwd(g, x, w, None)
+        timer = ops.ConvTimer(capacity=8)
+        ops.conv_timer = timer
+        try:
+            for _ in range(3):
+                got = ops.raw_conv_fwd(g, x, w, None)
+        finally:
+            ops.conv_timer = None
+        outer0, outer1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        outer0.record()
+        ops.raw_conv_fwd(g, x, w, None)
+        outer1.record()
+        torch.cuda.synchronize()
+        assert lib.vg_time_pending() == 0 and timer.untimed == 0
+        assert torch.equal(got, want)
+        (name, (n, ms, flops)), = timer.summary().items()
+        assert n == 3 and flops == 3 * 2.0 * N * g.Ho * g.Wo * Co * k * k * Ci
+        assert 0.0 < ms / 3 <= outer0.elapsed_time(outer1) * 1.5 + 0.05, (name, ms / 3, outer0.elapsed_time(outer1))
