@@ -727,6 +727,25 @@ __global__ void __launch_bounds__(NW * 64, NW == 8 ? 4 : 1) igemm_kernel(const I
     }
   }
   float* colp = outp + n0 + wn * TN * 32 + r;
+  // dgrad: the rows of a tile are pixels of one parity class, scattered over the output image. Each row's element
+  // offset is worked out once per block (two divisions per row) and left in LDS, which the k loop no longer needs,
+  // instead of thirty-two times per lane inside the store loop.
+  constexpr unsigned NO_ROW = 0xffffffffu;      // offsets stay below 2^31 (tensor size limit of the geometry check)
+  unsigned* row_off = reinterpret_cast<unsigned*>(smem);
+  if constexpr (MODE == MODE_DGRAD) {
+    __syncthreads();                            // every wave is done with the staged tiles
+    for (int rr = tid; rr < BM; rr += NT) {
+      const int row = m0 + rr;
+      unsigned off = NO_ROW;
+      if (row < M) {
+        const int n = vg_div_row(row, plane, inv_plane, fast), rem = row - n * plane;
+        const int ii = vg_div_row(rem, roww, inv_roww, fast), jj = rem - ii * roww;
+        off = (unsigned)((n * p.H + ii * p.sh + off_h) * p.W + jj * p.sw + off_w) * (unsigned)p.Ncols;
+      }
+      row_off[rr] = off;
+    }
+    __syncthreads();
+  }
 #pragma unroll
   for (int mi = 0; mi < TM; ++mi) {
     const int row_t = m0 + (wm * TM + mi) * 32 + 4 * h;      // first of the lane's 16 rows of this tile
@@ -736,13 +755,13 @@ __global__ void __launch_bounds__(NW * 64, NW == 8 ? 4 : 1) igemm_kernel(const I
     for (int e = 0; e < 16; ++e) {
       const int dr = (e & 3) + 8 * (e >> 2);
       const int row = row_t + dr;
-      if (row >= M) continue;
       float* rp;
       if constexpr (MODE == MODE_DGRAD) {
-        const int n = vg_div_row(row, plane, inv_plane, fast), rem = row - n * plane;
-        const int ii = vg_div_row(rem, roww, inv_roww, fast), jj = rem - ii * roww;
-        rp = tilep + (size_t)((n * p.H + ii * p.sh + off_h) * p.W + jj * p.sw + off_w) * p.Ncols;
+        const unsigned off = row_off[(wm * TM + mi) * 32 + 4 * h + dr];
+        if (off == NO_ROW) continue;
+        rp = tilep + off;
       } else {
+        if (row >= M) continue;
         rp = tilep + dr * p.Ncols;
       }
 #pragma unroll
