@@ -175,6 +175,17 @@ __device__ __forceinline__ float act_grad(float ref, int act, float slope) {
 }
 
 
+// The norm's pre-activation value, v = (x - mean) * (invstd * gamma) + beta, in ONE fixed sequence of operations (a
+// subtraction, a product for the scale, a fused multiply-add). The forward pass and the backward kernels that rebuild
+// the fused activation's slope mask from x instead of reading the activation's output both call this, so the mask is
+// the sign the forward pass saw, bit for bit.
+__device__ __forceinline__ float bn_affine(float a, float mu, float r, const float* gamma, float ga, const float* beta,
+                                           float be) {
+  const float sc = gamma ? r * ga : r;
+  const float d = a - mu;
+  return beta ? __builtin_fmaf(d, sc, be) : d * sc;
+}
+
 // ---- functors -------------------------------------------------------------------------------------
 struct SumF {  // colsum
   const float* x;
@@ -203,23 +214,30 @@ struct ShiftedMomentsF {  // sums of (x - x[0][c]) and its square
   }
 };
 
-struct BnBwdF {  // sum g, sum g*xhat with g = gy * act'(act_out) when an activation is fused behind the norm
-  const float *gy, *x, *mean, *invstd, *act_out;
+struct BnBwdF {  // sum g, sum g*xhat with g = gy * act'(.) when an activation is fused behind the norm: the mask comes
+                 // from the activation's output (act_out) or, without it, from the recomputed pre-activation
+  const float *gy, *x, *mean, *invstd, *act_out, *gamma, *beta;
   int act;
   float slope;
   template <int VEC>
   __device__ void eval(size_t off, int c, float (&acc)[2][VEC]) const {
     float g[VEC], a[VEC], mu[VEC], r[VEC];
     ldv<VEC>(gy + off, g);
+    ldv<VEC>(x + off, a);
+    ldv<VEC>(mean + c, mu);
+    ldv<VEC>(invstd + c, r);
     if (act_out) {
       float y[VEC];
       ldv<VEC>(act_out + off, y);
 #pragma unroll
       for (int e = 0; e < VEC; ++e) g[e] *= act_grad(y[e], act, slope);
+    } else if (act != VG_ACT_NONE) {
+      float ga[VEC], be[VEC];
+      if (gamma) ldv<VEC>(gamma + c, ga);
+      if (beta) ldv<VEC>(beta + c, be);
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) g[e] *= act_grad(bn_affine(a[e], mu[e], r[e], gamma, ga[e], beta, be[e]), act, slope);
     }
-    ldv<VEC>(x + off, a);
-    ldv<VEC>(mean + c, mu);
-    ldv<VEC>(invstd + c, r);
 #pragma unroll
     for (int e = 0; e < VEC; ++e) {
       const float xh = (a[e] - mu[e]) * r[e];
@@ -230,23 +248,29 @@ struct BnBwdF {  // sum g, sum g*xhat with g = gy * act'(act_out) when an activa
 };
 
 struct BnDbwdF {  // sum g, sum g*xhat, sum u, sum u*xhat, sum u*g   (g as in BnBwdF)
-  const float *gy, *x, *u, *mean, *invstd, *act_out;
+  const float *gy, *x, *u, *mean, *invstd, *act_out, *gamma, *beta;
   int act;
   float slope;
   template <int VEC>
   __device__ void eval(size_t off, int c, float (&acc)[5][VEC]) const {
     float g[VEC], a[VEC], uu[VEC], mu[VEC], r[VEC];
     ldv<VEC>(gy + off, g);
+    ldv<VEC>(x + off, a);
+    ldv<VEC>(u + off, uu);
+    ldv<VEC>(mean + c, mu);
+    ldv<VEC>(invstd + c, r);
     if (act_out) {
       float y[VEC];
       ldv<VEC>(act_out + off, y);
 #pragma unroll
       for (int e = 0; e < VEC; ++e) g[e] *= act_grad(y[e], act, slope);
+    } else if (act != VG_ACT_NONE) {
+      float ga[VEC], be[VEC];
+      if (gamma) ldv<VEC>(gamma + c, ga);
+      if (beta) ldv<VEC>(beta + c, be);
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) g[e] *= act_grad(bn_affine(a[e], mu[e], r[e], gamma, ga[e], beta, be[e]), act, slope);
     }
-    ldv<VEC>(x + off, a);
-    ldv<VEC>(u + off, uu);
-    ldv<VEC>(mean + c, mu);
-    ldv<VEC>(invstd + c, r);
 #pragma unroll
     for (int e = 0; e < VEC; ++e) {
       const float xh = (a[e] - mu[e]) * r[e];
@@ -307,12 +331,7 @@ __global__ void __launch_bounds__(256) bn_apply_kernel(const float* __restrict__
     if (gamma) ldv<VEC>(gamma + c, ga);
     if (beta) ldv<VEC>(beta + c, be);
 #pragma unroll
-    for (int e = 0; e < VEC; ++e) {
-      const float sc = gamma ? r[e] * ga[e] : r[e];
-      float v = (a[e] - mu[e]) * sc;
-      if (beta) v += be[e];
-      o[e] = act_apply(v, act, slope);
-    }
+    for (int e = 0; e < VEC; ++e) o[e] = act_apply(bn_affine(a[e], mu[e], r[e], gamma, ga[e], beta, be[e]), act, slope);
     stv<VEC>(y + i * VEC, o);
   }
 }
@@ -322,23 +341,29 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const float* __restri
                                                            const float* __restrict__ mean, const float* __restrict__ invstd,
                                                            const float* __restrict__ gamma, const float* __restrict__ sums,
                                                            float* __restrict__ gx, size_t nvec, int C, float inv_n,
-                                                           const float* __restrict__ act_out, int act, float slope) {
+                                                           const float* __restrict__ act_out, int act, float slope,
+                                                           const float* __restrict__ beta) {
   const int CG = C / VEC;
   const size_t stride = (size_t)gridDim.x * blockDim.x;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += stride) {
     const int c = (int)(i % CG) * VEC;
     float g[VEC], a[VEC], mu[VEC], r[VEC], ga[VEC], sg[VEC], sgx[VEC], o[VEC];
     ldv<VEC>(gy + i * VEC, g);
+    ldv<VEC>(x + i * VEC, a);
+    ldv<VEC>(mean + c, mu);
+    ldv<VEC>(invstd + c, r);
+    if (gamma) ldv<VEC>(gamma + c, ga);
     if (act_out) {
       float y[VEC];
       ldv<VEC>(act_out + i * VEC, y);
 #pragma unroll
       for (int e = 0; e < VEC; ++e) g[e] *= act_grad(y[e], act, slope);
+    } else if (act != VG_ACT_NONE) {
+      float be[VEC];
+      if (beta) ldv<VEC>(beta + c, be);
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) g[e] *= act_grad(bn_affine(a[e], mu[e], r[e], gamma, ga[e], beta, be[e]), act, slope);
     }
-    ldv<VEC>(x + i * VEC, a);
-    ldv<VEC>(mean + c, mu);
-    ldv<VEC>(invstd + c, r);
-    if (gamma) ldv<VEC>(gamma + c, ga);
     ldv<VEC>(sums + c, sg);
     ldv<VEC>(sums + C + c, sgx);
 #pragma unroll
@@ -375,7 +400,8 @@ __global__ void __launch_bounds__(256) bn_dbwd_apply_kernel(
     const float* __restrict__ gy, const float* __restrict__ x, const float* __restrict__ u, const float* __restrict__ v,
     const float* __restrict__ w, const float* __restrict__ mean, const float* __restrict__ invstd,
     const float* __restrict__ gamma, const float* __restrict__ sums5, float* __restrict__ d_gy, float* __restrict__ d_x,
-    size_t nvec, int C, float inv_n, const float* __restrict__ act_out, int act, float slope) {
+    size_t nvec, int C, float inv_n, const float* __restrict__ act_out, int act, float slope,
+    const float* __restrict__ beta) {
   const int CG = C / VEC;
   const size_t stride = (size_t)gridDim.x * blockDim.x;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += stride) {
@@ -383,22 +409,26 @@ __global__ void __launch_bounds__(256) bn_dbwd_apply_kernel(
     float g[VEC], a[VEC], uu[VEC], mu[VEC], r[VEC], ga[VEC], vv[VEC], ww[VEC];
     float s0[VEC], s1[VEC], s2[VEC], s3[VEC], s4[VEC], o1[VEC], o2[VEC], mk[VEC];
     ldv<VEC>(gy + i * VEC, g);
+    ldv<VEC>(x + i * VEC, a);
+    ldv<VEC>(u + i * VEC, uu);
+    ldv<VEC>(mean + c, mu);
+    ldv<VEC>(invstd + c, r);
+    if (gamma) ldv<VEC>(gamma + c, ga);
 #pragma unroll
     for (int e = 0; e < VEC; ++e) mk[e] = 1.f;
     if (act_out) {
       float y[VEC];
       ldv<VEC>(act_out + i * VEC, y);
 #pragma unroll
-      for (int e = 0; e < VEC; ++e) {
-        mk[e] = act_grad(y[e], act, slope);
-        g[e] *= mk[e];
-      }
+      for (int e = 0; e < VEC; ++e) mk[e] = act_grad(y[e], act, slope);
+    } else if (act != VG_ACT_NONE) {
+      float be[VEC];
+      if (beta) ldv<VEC>(beta + c, be);
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) mk[e] = act_grad(bn_affine(a[e], mu[e], r[e], gamma, ga[e], beta, be[e]), act, slope);
     }
-    ldv<VEC>(x + i * VEC, a);
-    ldv<VEC>(u + i * VEC, uu);
-    ldv<VEC>(mean + c, mu);
-    ldv<VEC>(invstd + c, r);
-    if (gamma) ldv<VEC>(gamma + c, ga);
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) g[e] *= mk[e];
     if (v) ldv<VEC>(v + c, vv);
     if (w) ldv<VEC>(w + c, ww);
     ldv<VEC>(sums5 + c, s0);
@@ -558,31 +588,33 @@ extern "C" int vg_bn_apply(const float* x, const float* mean, const float* invst
 }
 
 static int check_mask_act(const float* act_out, int act, const char* who) {
-  if (act_out && act != VG_ACT_RELU && act != VG_ACT_LRELU)
+  if (act != VG_ACT_NONE && act != VG_ACT_RELU && act != VG_ACT_LRELU)
     return vg_fail(VG_ERR_INVALID, "%s: only relu / leaky relu can be fused behind the norm", who);
+  if (act_out && act == VG_ACT_NONE)
+    return vg_fail(VG_ERR_INVALID, "%s: an activation output was passed without an activation code", who);
   return 0;
 }
 
 extern "C" int vg_bn_bwd_reduce(const float* gy, const float* x, const float* mean, const float* invstd, int M, int C,
                                 float* sums, void* ws, size_t ws_bytes, const float* act_out, int act, float slope,
-                                void* stream) {
+                                const float* gamma, const float* beta, void* stream) {
   VG_REQUIRE(gy && x && mean && invstd && sums && M > 0 && C > 0, "vg_bn_bwd_reduce: bad arguments");
   if (int e = check_mask_act(act_out, act, "vg_bn_bwd_reduce")) return e;
-  BnBwdF f{gy, x, mean, invstd, act_out, act, slope};
-  return run_colreduce<2>("vg_bn_bwd_reduce", f, M, C, all_aligned({gy, x, mean, invstd, act_out}), sums, ws, ws_bytes,
-                          (hipStream_t)stream);
+  BnBwdF f{gy, x, mean, invstd, act_out, gamma, beta, act, slope};
+  return run_colreduce<2>("vg_bn_bwd_reduce", f, M, C, all_aligned({gy, x, mean, invstd, act_out, gamma, beta}), sums, ws,
+                          ws_bytes, (hipStream_t)stream);
 }
 
 extern "C" int vg_bn_bwd_apply(const float* gy, const float* x, const float* mean, const float* invstd, const float* gamma,
                                const float* sums, float* gx, int M, int C, const float* act_out, int act, float slope,
-                               void* stream) {
+                               const float* beta, void* stream) {
   VG_REQUIRE(gy && x && mean && invstd && sums && gx && M > 0 && C > 0, "vg_bn_bwd_apply: bad arguments");
   if (int e = check_mask_act(act_out, act, "vg_bn_bwd_apply")) return e;
-  const bool v4 = C % 4 == 0 && all_aligned({gy, x, mean, invstd, gamma, sums, gx, act_out});
+  const bool v4 = C % 4 == 0 && all_aligned({gy, x, mean, invstd, gamma, sums, gx, act_out, beta});
   const size_t total = (size_t)M * C;
   const float inv_n = 1.0f / (float)M;
   VG_LAUNCH_VEC(bn_bwd_apply_kernel, v4, total, (hipStream_t)stream, gy, x, mean, invstd, gamma, sums, gx, nvec__, C, inv_n,
-                act_out, act, slope);
+                act_out, act, slope, beta);
   VG_CHECK_LAUNCH("vg_bn_bwd_apply");
   return VG_OK;
 }
@@ -599,26 +631,26 @@ extern "C" int vg_bn_bwd_eval(const float* gy, const float* invstd, const float*
 
 extern "C" int vg_bn_dbwd_reduce(const float* gy, const float* x, const float* u, const float* mean, const float* invstd,
                                  int M, int C, float* sums5, void* ws, size_t ws_bytes, const float* act_out, int act,
-                                 float slope, void* stream) {
+                                 float slope, const float* gamma, const float* beta, void* stream) {
   VG_REQUIRE(gy && x && u && mean && invstd && sums5 && M > 0 && C > 0, "vg_bn_dbwd_reduce: bad arguments");
   if (int e = check_mask_act(act_out, act, "vg_bn_dbwd_reduce")) return e;
-  BnDbwdF f{gy, x, u, mean, invstd, act_out, act, slope};
-  return run_colreduce<5>("vg_bn_dbwd_reduce", f, M, C, all_aligned({gy, x, u, mean, invstd, act_out}), sums5, ws, ws_bytes,
-                          (hipStream_t)stream);
+  BnDbwdF f{gy, x, u, mean, invstd, act_out, gamma, beta, act, slope};
+  return run_colreduce<5>("vg_bn_dbwd_reduce", f, M, C, all_aligned({gy, x, u, mean, invstd, act_out, gamma, beta}), sums5,
+                          ws, ws_bytes, (hipStream_t)stream);
 }
 
 extern "C" int vg_bn_dbwd_apply(const float* gy, const float* x, const float* u, const float* v, const float* w,
                                 const float* mean, const float* invstd, const float* gamma, const float* sums5, float* d_gy,
                                 float* d_x, float* d_gamma, int M, int C, const float* act_out, int act, float slope,
-                                void* stream) {
+                                const float* beta, void* stream) {
   VG_REQUIRE(gy && x && u && mean && invstd && sums5 && d_gy && d_x && M > 0 && C > 0, "vg_bn_dbwd_apply: bad arguments");
   if (int e = check_mask_act(act_out, act, "vg_bn_dbwd_apply")) return e;
-  const bool v4 = C % 4 == 0 && all_aligned({gy, x, u, v, w, mean, invstd, gamma, sums5, d_gy, d_x, act_out});
+  const bool v4 = C % 4 == 0 && all_aligned({gy, x, u, v, w, mean, invstd, gamma, sums5, d_gy, d_x, act_out, beta});
   const size_t total = (size_t)M * C;
   const float inv_n = 1.0f / (float)M;
   hipStream_t st = (hipStream_t)stream;
   VG_LAUNCH_VEC(bn_dbwd_apply_kernel, v4, total, st, gy, x, u, v, w, mean, invstd, gamma, sums5, d_gy, d_x, nvec__, C, inv_n,
-                act_out, act, slope);
+                act_out, act, slope, beta);
   VG_CHECK_LAUNCH("vg_bn_dbwd_apply");
   if (d_gamma) {
     hipLaunchKernelGGL(bn_dbwd_gamma_kernel, dim3((C + 255) / 256), dim3(256), 0, st, invstd, sums5, d_gamma, C, (float)M);

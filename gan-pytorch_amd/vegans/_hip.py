@@ -85,12 +85,12 @@ SIGNATURES = {
     "vg_bn_stats": (c_int, [_P, c_int, c_int, c_float, c_float, _P, _P, _P, _P, _P, _P, c_size_t, _P]),
     "vg_bn_invstd_from_var": (c_int, [_P, _P, c_int, c_float, _P]),
     "vg_bn_apply": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_float, _P]),
-    "vg_bn_bwd_reduce": (c_int, [_P, _P, _P, _P, c_int, c_int, _P, _P, c_size_t, _P, c_int, c_float, _P]),
-    "vg_bn_bwd_apply": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, c_int, _P, c_int, c_float, _P]),
+    "vg_bn_bwd_reduce": (c_int, [_P, _P, _P, _P, c_int, c_int, _P, _P, c_size_t, _P, c_int, c_float, _P, _P, _P]),
+    "vg_bn_bwd_apply": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, c_int, _P, c_int, c_float, _P, _P]),
     "vg_bn_bwd_eval": (c_int, [_P, _P, _P, _P, c_int, c_int, _P]),
-    "vg_bn_dbwd_reduce": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, _P, _P, c_size_t, _P, c_int, c_float, _P]),
+    "vg_bn_dbwd_reduce": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, _P, _P, c_size_t, _P, c_int, c_float, _P, _P, _P]),
     "vg_bn_dbwd_apply": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, _P, c_int, c_float,
-                                 _P]),
+                                 _P, _P]),
     "vg_act_fwd": (c_int, [_P, _P, c_size_t, c_int, c_float, _P]),
     "vg_act_bwd": (c_int, [_P, _P, _P, c_size_t, c_int, c_float, _P]),
     "vg_act_dbwd_ref": (c_int, [_P, _P, _P, _P, c_size_t, c_int, _P]),

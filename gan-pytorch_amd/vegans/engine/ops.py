@@ -549,11 +549,13 @@ def _bn_ws(m, c, device):
     return workspace(nbytes, device), nbytes
 
 
-def _act_args(y, act, slope):
-    """(act_out, act, slope) kernel arguments of a norm with a fused activation; no activation = null mask."""
+def _act_args(act, slope):
+    """(act_out, act, slope) kernel arguments of a norm's backward kernels. The slope mask of a fused activation is
+    rebuilt from the norm's input and affine parameters (act_out stays null), so the backward pass does not read the
+    activation's output."""
     if act == _hip.ACT_NONE:
         return None, _hip.ACT_NONE, c_float(0.0)
-    return _ptr(y), act, c_float(slope)
+    return None, act, c_float(slope)
 
 
 class AddFn(Function):
@@ -576,8 +578,9 @@ class AddFn(Function):
 
 
 class BatchNormTrainFn(Function):
-    """Training-mode batch norm, optionally with a ReLU / LeakyReLU applied in the same pass (`act`). With a fused
-    activation the output doubles as the slope mask of the backward pass, so no pre-activation tensor exists.
+    """Training-mode batch norm, optionally with a ReLU / LeakyReLU applied in the same pass (`act`). No
+    pre-activation tensor exists; the backward kernels rebuild the activation's slope mask from x, the batch statistics
+    and (gamma, beta) with the forward kernel's own instruction sequence, so they do not read the output either.
 
     Returns (y, tap). `tap` is an alias of the input that exists for the second derivative only: the first-order
     backward below is itself an operator of x (through the batch statistics), and when it is differentiated again
@@ -606,20 +609,20 @@ class BatchNormTrainFn(Function):
         ctx.act, ctx.slope = act, slope
         ctx.label = grads.ticket()
         tap = x_in.view_as(x_in)
-        ctx.save_for_backward(tap, gamma, beta, mean, invstd, y if act != _hip.ACT_NONE else None)
+        ctx.save_for_backward(tap, gamma, beta, mean, invstd)
         ctx.set_materialize_grads(False)
         return y, tap
 
     @staticmethod
     def backward(ctx, gy, gtap):
-        tap, gamma, beta, mean, invstd, y = ctx.saved_tensors
+        tap, gamma, beta, mean, invstd = ctx.saved_tensors
         lab = ctx.label
         gx = ggamma = gbeta = None
         if gy is not None:
-            # the activation's output only supplies a piecewise-constant mask: detached, so the second derivative does
-            # not come back to this operator through it
-            mask = y.detach() if y is not None else None
-            gx, ggamma, gbeta = BatchNormBwdFn.apply(gy, tap, gamma, mean, invstd, mask, ctx.act, ctx.slope, lab + (0,))
+            # beta only enters the piecewise-constant slope mask: detached, so no derivative is asked of it there
+            mask_beta = beta.detach() if beta is not None and ctx.act != _hip.ACT_NONE else None
+            gx, ggamma, gbeta = BatchNormBwdFn.apply(gy, tap, gamma, mean, invstd, mask_beta, ctx.act, ctx.slope,
+                                                     lab + (0,))
         if gtap is not None:
             gx = gtap if gx is None else AddFn.apply(gx, gtap)
         return (gx, grads.route(gamma, lab, ggamma) if gamma is not None else None,
@@ -629,34 +632,35 @@ class BatchNormTrainFn(Function):
 
 class BatchNormBwdFn(Function):
     """(gx, ggamma, gbeta) of training-mode batch norm as a function of (gy, x, gamma); mean/invstd are the batch
-    statistics of x (their dependence on x is part of the second derivative below). `act_out` is the output of the
-    fused activation (or None): it only supplies the piecewise-constant slope mask, so it carries no gradient."""
+    statistics of x (their dependence on x is part of the second derivative below). With a fused activation
+    (`act`), `mask_beta` is the norm's beta: together with x, the statistics and gamma it gives the sign of the
+    pre-activation, i.e. the piecewise-constant slope mask, which carries no gradient."""
 
     @staticmethod
-    def forward(ctx, gy, x, gamma, mean, invstd, act_out, act, slope, label=None):
-        ctx.save_for_backward(gy, x, gamma, mean, invstd, act_out)
+    def forward(ctx, gy, x, gamma, mean, invstd, mask_beta, act, slope, label=None):
+        ctx.save_for_backward(gy, x, gamma, mean, invstd, mask_beta)
         ctx.act, ctx.slope = act, slope
         ctx.label = _label(label)
         gy, x = to_nhwc(gy), to_nhwc(x)
         m, c = _rows_cols(x)
-        mask = _act_args(act_out, act, slope)
+        mask = _act_args(act, slope)
         sums = torch.empty((2, c), dtype=torch.float32, device=x.device)
         ws, nbytes = _bn_ws(m, c, x.device)
         call("vg_bn_bwd_reduce", _ptr(gy), _ptr(x), _ptr(mean), _ptr(invstd), m, c, _ptr(sums),
-             ctypes.c_void_p(ws.data_ptr()), c_size_t(nbytes), *mask, _stream())
+             ctypes.c_void_p(ws.data_ptr()), c_size_t(nbytes), *mask, _ptr(gamma), _ptr(mask_beta), _stream())
         gx = torch.empty_like(x)
         call("vg_bn_bwd_apply", _ptr(gy), _ptr(x), _ptr(mean), _ptr(invstd), _ptr(gamma), _ptr(sums), _ptr(gx), m, c,
-             *mask, _stream())
+             *mask, _ptr(mask_beta), _stream())
         ctx.set_materialize_grads(False)
         return gx, sums[1], sums[0]
 
     @staticmethod
     @once_differentiable
     def backward(ctx, u, v, w):
-        gy, x, gamma, mean, invstd, act_out = ctx.saved_tensors
+        gy, x, gamma, mean, invstd, mask_beta = ctx.saved_tensors
         gy, x = to_nhwc(gy), to_nhwc(x)
         m, c = _rows_cols(x)
-        mask = _act_args(act_out, ctx.act, ctx.slope)
+        mask = _act_args(ctx.act, ctx.slope)
         if u is None:
             u = torch.empty_like(x)
             call("vg_fill", _ptr(u), c_float(0.0), c_size_t(u.numel()), _stream())
@@ -666,12 +670,12 @@ class BatchNormBwdFn(Function):
         sums5 = torch.empty((5, c), dtype=torch.float32, device=x.device)
         ws, nbytes = _bn_ws(m, c, x.device)
         call("vg_bn_dbwd_reduce", _ptr(gy), _ptr(x), _ptr(u), _ptr(mean), _ptr(invstd), m, c, _ptr(sums5),
-             ctypes.c_void_p(ws.data_ptr()), c_size_t(nbytes), *mask, _stream())
+             ctypes.c_void_p(ws.data_ptr()), c_size_t(nbytes), *mask, _ptr(gamma), _ptr(mask_beta), _stream())
         d_gy = torch.empty_like(x)
         d_x = torch.empty_like(x)
         d_gamma = torch.empty(c, dtype=torch.float32, device=x.device) if gamma is not None else None
         call("vg_bn_dbwd_apply", _ptr(gy), _ptr(x), _ptr(u), _ptr(v), _ptr(w), _ptr(mean), _ptr(invstd), _ptr(gamma),
-             _ptr(sums5), _ptr(d_gy), _ptr(d_x), _ptr(d_gamma), m, c, *mask, _stream())
+             _ptr(sums5), _ptr(d_gy), _ptr(d_x), _ptr(d_gamma), m, c, *mask, _ptr(mask_beta), _stream())
         if gamma is not None:
             d_gamma = grads.route(gamma, ctx.label, d_gamma)
         return d_gy, d_x, d_gamma, None, None, None, None, None, None
@@ -710,7 +714,8 @@ class BatchNormEvalFn(Function):
             sums = torch.empty((2, c), dtype=torch.float32, device=x.device)
             ws, nbytes = _bn_ws(m, c, x.device)
             call("vg_bn_bwd_reduce", _ptr(gy), _ptr(x), _ptr(mean), _ptr(invstd), m, c, _ptr(sums),
-                 ctypes.c_void_p(ws.data_ptr()), c_size_t(nbytes), None, _hip.ACT_NONE, c_float(0.0), _stream())
+                 ctypes.c_void_p(ws.data_ptr()), c_size_t(nbytes), None, _hip.ACT_NONE, c_float(0.0), None, None,
+                 _stream())
             ggamma = grads.route(gamma, ctx.label, sums[1]) if ctx.has_affine[0] else None
             gbeta = grads.route(beta, ctx.label, sums[0]) if ctx.has_affine[1] else None
         return gx, ggamma, gbeta, None, None, None, None, None

@@ -199,14 +199,17 @@ int vg_bn_apply(const float* x, const float* mean, const float* invstd, const fl
                 const float* beta, float* y, int M, int C, int act, float slope, void* stream);
 /* training-mode backward: sums[0:C] = sum gy, sums[C:2C] = sum gy*xhat (=> gbeta, ggamma), then
  * gx = gamma*invstd*(gy - mean(gy) - xhat*mean(gy*xhat)) */
-/* When a ReLU / LeakyReLU is fused behind the norm (vg_bn_apply with act), pass the fused OUTPUT as act_out: the
- * incoming gradient is then multiplied by the activation's slope mask on the fly (act_out null = no activation). */
+/* When a ReLU / LeakyReLU is fused behind the norm (vg_bn_apply with act), pass its code and slope: the incoming
+ * gradient is then multiplied by the activation's slope mask on the fly. The mask is read off the fused OUTPUT when
+ * act_out is given; with act_out null it is rebuilt from x as the sign of (x - mean) * (invstd * gamma) + beta, computed
+ * by the very instruction sequence vg_bn_apply uses (gamma, beta: the norm's affine parameters, nullable as there), so
+ * the backward pass reads one activation-sized tensor less. act = VG_ACT_NONE: no activation. */
 int vg_bn_bwd_reduce(const float* gy, const float* x, const float* mean, const float* invstd, int M, int C,
                      float* sums, void* workspace, size_t workspace_bytes, const float* act_out, int act, float slope,
-                     void* stream);
+                     const float* gamma, const float* beta, void* stream);
 int vg_bn_bwd_apply(const float* gy, const float* x, const float* mean, const float* invstd,
                     const float* gamma, const float* sums, float* gx, int M, int C, const float* act_out, int act,
-                    float slope, void* stream);
+                    float slope, const float* beta, void* stream);
 /* eval-mode backward: gx = gy * gamma * invstd */
 int vg_bn_bwd_eval(const float* gy, const float* invstd, const float* gamma, float* gx, int M, int C,
                    void* stream);
@@ -216,11 +219,11 @@ int vg_bn_bwd_eval(const float* gy, const float* invstd, const float* gamma, flo
  * Outputs: d_gy [M][C], d_x [M][C], d_gamma [C]. */
 int vg_bn_dbwd_reduce(const float* gy, const float* x, const float* u, const float* mean, const float* invstd,
                       int M, int C, float* sums5, void* workspace, size_t workspace_bytes, const float* act_out, int act,
-                      float slope, void* stream);
+                      float slope, const float* gamma, const float* beta, void* stream);
 int vg_bn_dbwd_apply(const float* gy, const float* x, const float* u, const float* v, const float* w,
                      const float* mean, const float* invstd, const float* gamma, const float* sums5,
                      float* d_gy, float* d_x, float* d_gamma, int M, int C, const float* act_out, int act, float slope,
-                     void* stream);
+                     const float* beta, void* stream);
 
 int vg_act_fwd(const float* x, float* y, size_t n, int act, float slope, void* stream);
 /* gx = gy * act'(.) ; `ref` is the forward INPUT for RELU/LRELU and the forward OUTPUT for TANH/SIGMOID */

@@ -746,3 +746,61 @@ def test_kernel_timing_events_hold_the_kernels_own_duration(gpu):
         (name, (n, ms, flops)), = timer.summary().items()
         assert n == 3 and flops == 3 * 2.0 * N * g.Ho * g.Wo * Co * k * k * Ci
         assert 0.0 < ms / 3 <= outer0.elapsed_time(outer1) * 1.5 + 0.05, (name, ms / 3, outer0.elapsed_time(outer1))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("act,slope", [("relu", 0.0), ("lrelu", 0.2)])
+def test_bn_backward_mask_rebuilt_from_input_equals_mask_from_output(gpu, act, slope):
+    """The norm's backward kernels rebuild the fused activation's slope mask from (x, mean, invstd, gamma, beta); the
+    result must be bit-identical to reading the mask off the forward pass's output, also for pre-activations that are
+    tiny, exactly zero, or whose sign hangs on the last rounding of the affine map."""
+    import ctypes
+    from ctypes import c_float, c_size_t
+    from vegans import _hip
+    from vegans.engine import ops
+    from vegans.engine.ops import _ptr, _stream, call
+    code = {"relu": _hip.ACT_RELU, "lrelu": _hip.ACT_LRELU}[act]
+    torch.manual_seed(11)
+    m, c = 4096, 64
+    x = torch.randn(m, c, device="cuda")
+    gamma = torch.randn(c, device="cuda")
+    beta = torch.randn(c, device="cuda") * 0.1
+    mean = torch.empty(c, device="cuda")
+    invstd = torch.empty(c, device="cuda")
+    nbytes = _hip.load().vg_bn_workspace_bytes(m, c)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+    wsp = ctypes.c_void_p(ws.data_ptr())
+    call("vg_bn_stats", _ptr(x), m, c, c_float(1e-5), c_float(0.1), _ptr(mean), _ptr(invstd), None, None, None, wsp,
+         c_size_t(nbytes), _stream())
+    # rows whose pre-activation is zero or within an ulp of it: x = mean - beta / (invstd * gamma), and neighbours
+    root = mean - beta / (invstd * gamma)
+    x[0] = root
+    x[1] = torch.nextafter(root, root + 1)
+    x[2] = torch.nextafter(root, root - 1)
+    x[3] = mean
+    y = torch.empty_like(x)
+    call("vg_bn_apply", _ptr(x), _ptr(mean), _ptr(invstd), _ptr(gamma), _ptr(beta), _ptr(y), m, c, code, c_float(slope),
+         _stream())
+    gy = torch.randn(m, c, device="cuda")
+    u = torch.randn(m, c, device="cuda")
+    out = {}
+    for how, (yo, ga, be) in {"output": (y, None, None), "input": (None, gamma, beta)}.items():
+        sums = torch.empty(2, c, device="cuda")
+        gx = torch.empty_like(x)
+        call("vg_bn_bwd_reduce", _ptr(gy), _ptr(x), _ptr(mean), _ptr(invstd), m, c, _ptr(sums), wsp, c_size_t(nbytes),
+             _ptr(yo), code, c_float(slope), _ptr(ga), _ptr(be), _stream())
+        call("vg_bn_bwd_apply", _ptr(gy), _ptr(x), _ptr(mean), _ptr(invstd), _ptr(gamma), _ptr(sums), _ptr(gx), m, c,
+             _ptr(yo), code, c_float(slope), _ptr(be), _stream())
+        sums5 = torch.empty(5, c, device="cuda")
+        d_gy, d_x, d_gamma = torch.empty_like(x), torch.empty_like(x), torch.empty(c, device="cuda")
+        call("vg_bn_dbwd_reduce", _ptr(gy), _ptr(x), _ptr(u), _ptr(mean), _ptr(invstd), m, c, _ptr(sums5), wsp,
+             c_size_t(nbytes), _ptr(yo), code, c_float(slope), _ptr(ga), _ptr(be), _stream())
+        call("vg_bn_dbwd_apply", _ptr(gy), _ptr(x), _ptr(u), None, None, _ptr(mean), _ptr(invstd), _ptr(gamma),
+             _ptr(sums5), _ptr(d_gy), _ptr(d_x), _ptr(d_gamma), m, c, _ptr(yo), code, c_float(slope), _ptr(be), _stream())
+        torch.cuda.synchronize()
+        out[how] = (sums, gx, sums5, d_gy, d_x, d_gamma)
+    names = ("sums", "gx", "sums5", "d_gy", "d_x", "d_gamma")
+    for name, a, b in zip(names, out["output"], out["input"]):
+        assert torch.equal(a, b), (name, int((a != b).sum()), float((a - b).abs().max()))
+    # the constructed rows do sit on the kink: tiny pre-activations of both signs
+    assert float(y[:3].abs().max()) < 1e-4 and bool((y[:3] > 0).any()) and bool((y[:3] <= 0).any())

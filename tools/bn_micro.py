@@ -46,13 +46,22 @@ def main():
         wsp = ctypes.c_void_p(ws.data_ptr())
         t_stats = timed(lambda: call("vg_bn_stats", _ptr(x), m, c, c_float(1e-5), c_float(0.1), _ptr(mean), _ptr(invstd),
                                      None, None, None, wsp, c_size_t(nbytes), _stream()))
+        beta = torch.zeros(c, device=dev)
+        # slope mask read off the activation's output (three activation-sized reads) ...
         t_red = timed(lambda: call("vg_bn_bwd_reduce", _ptr(gy), _ptr(x), _ptr(mean), _ptr(invstd), m, c, _ptr(sums), wsp,
-                                   c_size_t(nbytes), _ptr(y), _hip.ACT_LRELU, c_float(0.2), _stream()))
+                                   c_size_t(nbytes), _ptr(y), _hip.ACT_LRELU, c_float(0.2), None, None, _stream()))
         t_app = timed(lambda: call("vg_bn_bwd_apply", _ptr(gy), _ptr(x), _ptr(mean), _ptr(invstd), _ptr(gamma), _ptr(sums),
-                                   _ptr(gx), m, c, _ptr(y), _hip.ACT_LRELU, c_float(0.2), _stream()))
+                                   _ptr(gx), m, c, _ptr(y), _hip.ACT_LRELU, c_float(0.2), None, _stream()))
+        # ... and rebuilt from x (two reads): what the training step runs
+        t_red2 = timed(lambda: call("vg_bn_bwd_reduce", _ptr(gy), _ptr(x), _ptr(mean), _ptr(invstd), m, c, _ptr(sums), wsp,
+                                    c_size_t(nbytes), None, _hip.ACT_LRELU, c_float(0.2), _ptr(gamma), _ptr(beta), _stream()))
+        t_app2 = timed(lambda: call("vg_bn_bwd_apply", _ptr(gy), _ptr(x), _ptr(mean), _ptr(invstd), _ptr(gamma), _ptr(sums),
+                                    _ptr(gx), m, c, None, _hip.ACT_LRELU, c_float(0.2), _ptr(beta), _stream()))
         mb = m * c * 4 / 1e6
-        print("M=%7d C=%3d (%5.1f MB/tensor)  stats %6.1f us %5.0f GB/s | bwd reduce %6.1f us %5.0f GB/s | bwd apply %6.1f us "
-              "%5.0f GB/s" % (m, c, mb, t_stats, mb / t_stats * 1e3, t_red, 3 * mb / t_red * 1e3, t_app, 4 * mb / t_app * 1e3))
+        print("M=%7d C=%3d (%5.1f MB/tensor)  stats %6.1f us %5.0f GB/s | bwd reduce %6.1f us %5.0f GB/s, mask from x %6.1f us "
+              "%5.0f GB/s | bwd apply %6.1f us %5.0f GB/s, mask from x %6.1f us %5.0f GB/s"
+              % (m, c, mb, t_stats, mb / t_stats * 1e3, t_red, 3 * mb / t_red * 1e3, t_red2, 2 * mb / t_red2 * 1e3,
+                 t_app, 4 * mb / t_app * 1e3, t_app2, 3 * mb / t_app2 * 1e3))
 
 
 if __name__ == "__main__":
