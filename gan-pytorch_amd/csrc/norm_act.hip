@@ -21,9 +21,15 @@ inline int row_blocks(int M) {
 }
 
 // ---- generic column reduction: partial[v][b][c] = sum over the rows of block b of f_v(row, c) -------------
+// A thread adds its own rows (8 ... 32 terms) in f32; from there on - across the threads of a block, across the blocks,
+// into the epilogue - the sums are carried in double precision and rounded to f32 once. The long part of such a sum
+// (10^3 ... 10^5 rows per channel) therefore adds no rounding of its own, as in the reference's CPU kernels, which
+// accumulate batch statistics and the BatchNorm backward sums in double: a gradient sum whose terms nearly cancel
+// (sum g over a channel of the critic) otherwise loses three to four digits, and every gradient below that layer
+// inherits the error through mean(g). The per-element work is unchanged, so the kernels run as fast as before.
 template <int NV, int VEC, class F>
-__global__ void __launch_bounds__(256) colreduce_partial(F f, int M, int C, int rows_per_block, float* partial) {
-  __shared__ float red[NV * VEC * 256];
+__global__ void __launch_bounds__(256) colreduce_partial(F f, int M, int C, int rows_per_block, double* partial) {
+  __shared__ double red[NV * VEC * 256];
   const int CG = C / VEC;
   constexpr int CGB = kChunkChannels / VEC;          // channel groups per block
   const int cg_lo = blockIdx.y * CGB, cg_hi = min(cg_lo + CGB, CG);
@@ -49,14 +55,14 @@ __global__ void __launch_bounds__(256) colreduce_partial(F f, int M, int C, int 
 #pragma unroll
     for (int v = 0; v < NV; ++v)
 #pragma unroll
-      for (int e = 0; e < VEC; ++e) red[(v * VEC + e) * 256 + tid] = acc[v][e];
+      for (int e = 0; e < VEC; ++e) red[(v * VEC + e) * 256 + tid] = (double)acc[v][e];
     __syncthreads();
     if (ty == 0 && cg < cg_hi) {
 #pragma unroll
       for (int v = 0; v < NV; ++v)
 #pragma unroll
         for (int e = 0; e < VEC; ++e) {
-          float s = 0.f;
+          double s = 0.0;
           for (int y = 0; y < TY; ++y) s += red[(v * VEC + e) * 256 + y * TX + tx];
           partial[((size_t)v * nblk + blockIdx.x) * C + cg * VEC + e] = s;
         }
@@ -70,20 +76,20 @@ struct StoreSumsE {   // plain result: out[v][c]
   float* out;
   int C;
   template <int NV>
-  __device__ void operator()(int c, const float (&s)[NV]) const {
+  __device__ void operator()(int c, const double (&s)[NV]) const {
 #pragma unroll
-    for (int v = 0; v < NV; ++v) out[(size_t)v * C + c] = s[v];
+    for (int v = 0; v < NV; ++v) out[(size_t)v * C + c] = (float)s[v];
   }
 };
 
 template <int NV, class E>
-__global__ void __launch_bounds__(256) colreduce_final(const float* partial, int nblk, int C, E epilogue) {
-  __shared__ float red[NV * 256];
+__global__ void __launch_bounds__(256) colreduce_final(const double* partial, int nblk, int C, E epilogue) {
+  __shared__ double red[NV * 256];
   const int cl = threadIdx.x & 15, q = threadIdx.x >> 4;
   const int c = blockIdx.x * 16 + cl;
-  float acc[NV];
+  double acc[NV];
 #pragma unroll
-  for (int v = 0; v < NV; ++v) acc[v] = 0.f;
+  for (int v = 0; v < NV; ++v) acc[v] = 0.0;
   if (c < C) {
 #pragma unroll 4
     for (int b = q; b < nblk; b += 16) {
@@ -95,11 +101,11 @@ __global__ void __launch_bounds__(256) colreduce_final(const float* partial, int
   for (int v = 0; v < NV; ++v) red[v * 256 + threadIdx.x] = acc[v];
   __syncthreads();
   if (q == 0 && c < C) {
-    float tot[NV];
+    double tot[NV];
 #pragma unroll
     for (int v = 0; v < NV; ++v) {
-      const float* rr = red + v * 256 + cl;
-      float s = 0.f;
+      const double* rr = red + v * 256 + cl;
+      double s = 0.0;
 #pragma unroll
       for (int j = 0; j < 16; ++j) s += rr[16 * j];
       tot[v] = s;
@@ -112,17 +118,18 @@ template <int NV, class F, class E>
 int run_colreduce_with(const char* who, F f, int M, int C, bool vec_ok, E epilogue, void* ws, size_t ws_bytes,
                        hipStream_t st) {
   const int nb = row_blocks(M);
-  const size_t need = (size_t)NV * nb * C * sizeof(float);
-  if (!ws || ws_bytes < need) return vg_fail(VG_ERR_WORKSPACE, "%s: workspace of %zu bytes required, got %zu", who, need, ws_bytes);
+  const size_t need = (size_t)NV * nb * C * sizeof(double);
+  if (!ws || ws_bytes < need || (reinterpret_cast<uintptr_t>(ws) & 7u))
+    return vg_fail(VG_ERR_WORKSPACE, "%s: workspace of %zu bytes (8-byte aligned) required, got %zu", who, need, ws_bytes);
   const int rpb = (M + nb - 1) / nb;
-  float* partial = (float*)ws;
+  double* partial = (double*)ws;
   const dim3 grid(nb, (C + kChunkChannels - 1) / kChunkChannels);
   if (vec_ok && C % 4 == 0)
     hipLaunchKernelGGL((colreduce_partial<NV, 4, F>), grid, dim3(256), 0, st, f, M, C, rpb, partial);
   else
     hipLaunchKernelGGL((colreduce_partial<NV, 1, F>), grid, dim3(256), 0, st, f, M, C, rpb, partial);
   VG_CHECK_LAUNCH(who);
-  hipLaunchKernelGGL((colreduce_final<NV, E>), dim3((C + 15) / 16), dim3(256), 0, st, (const float*)partial, nb, C, epilogue);
+  hipLaunchKernelGGL((colreduce_final<NV, E>), dim3((C + 15) / 16), dim3(256), 0, st, (const double*)partial, nb, C, epilogue);
   VG_CHECK_LAUNCH(who);
   return VG_OK;
 }
@@ -293,17 +300,18 @@ struct BnFinalizeE {
   float *mean, *invstd, *running_mean, *running_var;
   long long* num_batches_tracked;
   template <int NV>
-  __device__ void operator()(int c, const float (&s)[NV]) const {
-    const float n = (float)M;
-    const float s1 = s[0] / n;
-    float var = s[1] / n - s1 * s1;
-    var = var < 0.f ? 0.f : var;
-    const float mu = x[c] + s1;
+  __device__ void operator()(int c, const double (&s)[NV]) const {
+    const double n = (double)M;
+    const double s1 = s[0] / n;
+    double var = s[1] / n - s1 * s1;
+    var = var < 0.0 ? 0.0 : var;
+    const float mu = (float)((double)x[c] + s1);
+    const float varf = (float)var;
     mean[c] = mu;
-    invstd[c] = 1.0f / sqrtf(var + eps);
+    invstd[c] = 1.0f / sqrtf(varf + eps);
     if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mu;
     if (running_var) {
-      const float unbiased = M > 1 ? var * (n / (n - 1.f)) : var;
+      const float unbiased = M > 1 ? (float)(var * (n / (n - 1.0))) : varf;
       running_var[c] = (1.f - momentum) * running_var[c] + momentum * unbiased;
     }
     if (num_batches_tracked && c == 0) *num_batches_tracked += 1;
@@ -547,12 +555,12 @@ inline bool all_aligned(std::initializer_list<const void*> ps) {
 
 extern "C" size_t vg_bn_workspace_bytes(int M, int C) {
   if (M <= 0 || C <= 0) return 0;
-  return (size_t)5 * row_blocks(M) * C * sizeof(float) + (size_t)5 * C * sizeof(float);
+  return (size_t)5 * row_blocks(M) * C * sizeof(double) + (size_t)5 * C * sizeof(float);
 }
 
 extern "C" size_t vg_colsum_workspace_bytes(int M, int C) {
   if (M <= 0 || C <= 0) return 0;
-  return (size_t)row_blocks(M) * C * sizeof(float);
+  return (size_t)row_blocks(M) * C * sizeof(double);
 }
 
 extern "C" int vg_colsum(const float* x, float* out, int M, int C, void* ws, size_t ws_bytes, void* stream) {

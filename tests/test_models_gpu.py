@@ -790,3 +790,94 @@ def test_lsgan_full_width_dcgan128_vs_oracle(gpu, capsys):
         print("\nDCGAN-128 LSGAN/Adam full width, batch %d, teacher-forced: worst loss error %.2e of its own value, worst "
               "outlier share %.2e" % (B, stats["loss"], stats["share"]))
     assert not stats["problems"], "\n".join(stats["problems"][:40])
+
+
+def test_pix2pix_full_size_unet256_vs_oracle(gpu, capsys):
+    """The image-to-image configuration at its real size (ConditionalPix2Pix, U-Net-256 with 8 down / 8 up blocks and
+    skip concatenations at width 64, 70x70 PatchGAN at width 64, 3x256x256 images, 2 latent planes) at a batch the CPU
+    oracle finishes in seconds: one iteration, teacher-forced before every sub-step. The reference-generated fixture of
+    this topology (`pix2pix_unet`) is 32x32 at width 4.
+
+    Losses: 1e-4 of their own value (floor 1e-2) against the fp32 oracle.
+
+    Gradients: at batch 2 the bottleneck blocks normalise over 2 ... 128 samples per channel and the problem is badly
+    conditioned: the fp32 ORACLE's own gradients are 1e-3 ... 2e-3 (l2 norm of the error over l2 norm of the tensor) away
+    from the same code evaluated in float64, so two fp32 implementations cannot agree to 1e-4 here. The assertion is
+    therefore made against the float64 gradients: for every parameter tensor the engine's distance is at most 1e-4 or
+    six times the fp32 oracle's own distance (measured: 1.1 ... 3.5 times; the reference's CPU kernels accumulate
+    shorter chains), and never more than 2e-2.
+
+    Parameters after the Adam step: the first step moves every element by lr * g / (|g| + 1e-8), i.e. by the full +-lr
+    also where the gradient is rounding noise, so single elements differ by up to 2 lr between two correct
+    implementations: no element may differ by more than that, and at most 1 % of a tensor's elements may lie beyond 1e-4
+    of its scale (measured: up to 0.45 %)."""
+    from unittest import mock
+    import bench_configs as cfg
+    from oracle.restated import OracleGAN
+    case = dict(cls="ConditionalPix2Pix", algo="pix2pix", x_dim=(3, 256, 256), z_dim=2, y_dim=(3, 256, 256),
+                fixed_noise_size=2)
+
+    def nets():
+        return (cfg.seeded_init(cfg.UNet(in_channels=2 + 3, out_channels=3, width=64, depth=8), 1, 0.05),
+                cfg.seeded_init(cfg.patchgan_discriminator(in_channels=6, width=64), 2, 0.05), None)
+
+    torch.manual_seed(3)
+    np.random.seed(3)
+    Go, Do, _ = nets()
+    oracle = OracleGAN("pix2pix", Go, Do, case["x_dim"], case["z_dim"], y_dim=case["y_dim"], fixed_noise_size=2)
+    torch.manual_seed(3)
+    np.random.seed(3)
+    model = _build_model(case, nets())
+    model.use_step_graph = False
+    model._create_steps(None)
+    model.train()
+    oracle._set_mode(True)
+    B = 2
+    # smooth images that differ from each other at every scale (uniform noise images give every image nearly the same
+    # deep features, which makes the batch statistics of the inner blocks even worse conditioned)
+    g = torch.Generator().manual_seed(5)
+    low = torch.rand(2 * B, 3, 8, 8, generator=g)
+    big = torch.nn.functional.interpolate(low, size=(256, 256), mode="bilinear", align_corners=False)
+    big = (big + 0.1 * torch.rand(2 * B, 3, 256, 256, generator=g)).clamp(0, 1)
+    X, y = big[:B].contiguous(), big[B:].contiguous()
+    Z = torch.randn(B, 2, generator=torch.Generator().manual_seed(12))
+    batch = (model._to_device(X.numpy()), model._to_device(y.numpy()), Z.to("cuda"))
+    stats = {"loss": 0.0, "share": 0.0, "outliers": {}, "problems": []}
+    skip = {net: gu.shadowed_keys(model.neural_nets[net].network) for net in oracle.nets}
+    worst_ratio, worst_grad = 0.0, 0.0
+    for who in oracle.nets:
+        _sync_from_oracle(oracle, model)
+        # the float64 yardstick, on the state both sides start this sub-step from
+        twin = object.__new__(type(oracle))
+        twin.__dict__.update(oracle.__dict__)
+        twin.nets = {k: copy.deepcopy(v).double() for k, v in oracle.nets.items()}
+        twin._set_mode(True)
+        with mock.patch.object(torch.Tensor, "float", lambda self: self.double()):
+            loss64 = twin.losses(who, X.double(), Z.double(), y.double(), None)[who]
+        g64 = torch.autograd.grad(loss64, list(twin.nets[who].parameters()))
+        del twin
+        want = oracle.sub_step(who, X, Z.clone(), y, None)
+        got = _engine_sub_step(model, who, *batch)
+        for (k, po), pm, ref in zip(oracle.nets[who].named_parameters(), model.neural_nets[who].network.parameters(), g64):
+            if k in skip[who]:
+                continue
+            norm = max(float(ref.norm()), 1e-30)
+            d_oracle = float((po.grad.double() - ref).norm()) / norm
+            d_engine = float((pm.grad.detach().cpu().double() - ref).norm()) / norm
+            worst_grad = max(worst_grad, d_engine)
+            if d_engine > REL:
+                worst_ratio = max(worst_ratio, d_engine / max(d_oracle, 1e-30))
+            if d_engine > max(REL, 6.0 * d_oracle) or d_engine > 2e-2:
+                stats["problems"].append("pix2pix-256 %s gradient of %s: %.2e from float64 (fp32 oracle: %.2e)"
+                                         % (who, k, d_engine, d_oracle))
+        _compare_sub_step("pix2pix-256 %s" % who, want, got, oracle, model, list(oracle.nets), skip, 1e-2, 1e-2, stats)
+        lr = model.optimizers[who].param_groups[0]["lr"]
+        for (k, po), pm in zip(oracle.nets[who].named_parameters(), model.neural_nets[who].network.parameters()):
+            off = float((po.detach().double() - pm.detach().cpu().double()).abs().max())
+            if off > 2.0 * lr * 1.001 and k not in skip[who]:
+                stats["problems"].append("pix2pix-256 %s %s: an element is %.3e from the oracle's, more than 2 lr" % (who, k, off))
+    with capsys.disabled():
+        print("\npix2pix U-Net-256 + PatchGAN full width, batch %d, teacher-forced: worst loss error %.2e of its own "
+              "value; gradients: worst distance from float64 %.2e (l2), at most %.1f times the fp32 oracle's own; worst "
+              "outlier share after the Adam step %.2e" % (B, stats["loss"], worst_grad, worst_ratio, stats["share"]))
+    assert not stats["problems"], "\n".join(stats["problems"][:40])
