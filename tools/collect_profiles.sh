@@ -1,5 +1,5 @@
 #!/bin/bash
-# Collects, on the GPU box, what profiles/round2_* are made from: the benchmark line, a rocprofv3 kernel trace with
+# Collects, on the GPU box, what the summaries under profiles/ are made from: the benchmark line, a rocprofv3 kernel trace with
 # statistics of the same command, and three counter passes (each in a run of its own) of a short eager run.
 # usage: bash tools/collect_profiles.sh <tag>      (run from the repository root; writes under gpurun_out/<tag>_*)
 set -e
