@@ -12,9 +12,30 @@ extern "C" int vg_conv2d_dgrad(const vg_conv_geom* g, const float* gy, const flo
   return vg_conv2d_dgrad_prec(g, gy, w, bias, gx, VG_PREC_F32, nullptr, 0, nullptr, nullptr, stream);
 }
 
+static int conv_dgrad_impl(const vg_conv_geom* g, const float* gy, const float* w, const float* bias, float* gx,
+                           int precision, void* workspace, size_t workspace_bytes, const void* gy_planes,
+                           const void* w_planes, double* stats, int* stats_written, void* stream);
+
 extern "C" int vg_conv2d_dgrad_prec(const vg_conv_geom* g, const float* gy, const float* w, const float* bias,
                                     float* gx, int precision, void* workspace, size_t workspace_bytes, const void* gy_planes,
                                     const void* w_planes, void* stream) {
+  return conv_dgrad_impl(g, gy, w, bias, gx, precision, workspace, workspace_bytes, gy_planes, w_planes, nullptr, nullptr,
+                         stream);
+}
+
+extern "C" int vg_conv2d_dgrad_bnstats(const vg_conv_geom* g, const float* gy, const float* w, const float* bias, float* gx,
+                                       void* stats, size_t stats_bytes, int* stats_written, void* stream) {
+  VG_REQUIRE(stats && stats_written && vg_aligned16(stats), "vg_conv2d_dgrad_bnstats: null or misaligned statistics buffer");
+  if (stats_bytes < vg_conv2d_bnstats_workspace_bytes(1, g))
+    return vg_fail(VG_ERR_WORKSPACE, "vg_conv2d_dgrad_bnstats: statistics buffer of %zu bytes required, got %zu",
+                   vg_conv2d_bnstats_workspace_bytes(1, g), stats_bytes);
+  return conv_dgrad_impl(g, gy, w, bias, gx, VG_PREC_F32, nullptr, 0, nullptr, nullptr, (double*)stats, stats_written, stream);
+}
+
+static int conv_dgrad_impl(const vg_conv_geom* g, const float* gy, const float* w, const float* bias, float* gx,
+                           int precision, void* workspace, size_t workspace_bytes, const void* gy_planes,
+                           const void* w_planes, double* stats, int* stats_written, void* stream) {
+  if (stats_written) *stats_written = 0;
   if (int e = vg_check_geom(g, "vg_conv2d_dgrad")) return e;
   if (precision < VG_PREC_F32 || precision > VG_PREC_F32_SPLIT)
     return vg_fail(VG_ERR_INVALID, "vg_conv2d_dgrad: unknown precision %d", precision);
@@ -61,6 +82,16 @@ extern "C" int vg_conv2d_dgrad_prec(const vg_conv_geom* g, const float* gy, cons
   }
   if (igemm_set_operands(p, (long long)g->N * g->Ho * g->Wo * g->Co, (long long)g->Co * g->kh * g->kw * g->Ci))
     return vg_fail(VG_ERR_INVALID, "vg_conv2d_dgrad: the MFMA kernels address operands with 31-bit byte offsets; gy or w is 2 GiB or larger");
+  if (stats) {   // with column statistics where such a kernel exists for the plan, else plainly
+    p.stats = stats;
+    p.stats_tiles = p.mtiles * g->sh * g->sw;
+    if (igemm_launch<MODE_DGRAD, true>(p, bm, bn, va, vb, grid, (hipStream_t)stream, precision) == 0) {
+      VG_CHECK_LAUNCH("vg_conv2d_dgrad(statistics)");
+      *stats_written = 1;
+      return VG_OK;
+    }
+    p.stats = nullptr;
+  }
   if (igemm_launch<MODE_DGRAD, true>(p, bm, bn, va, vb, grid, (hipStream_t)stream, precision) != 0)
     return vg_fail(VG_ERR_INVALID, "vg_conv2d_dgrad: no kernel variant for bn=%d va=%d vb=%d", bn, va, vb);
   VG_CHECK_LAUNCH("vg_conv2d_dgrad");

@@ -32,9 +32,54 @@ extern "C" int vg_conv2d_fwd(const vg_conv_geom* g, const float* x, const float*
   return vg_conv2d_fwd_prec(g, x, w, bias, y, VG_PREC_F32, nullptr, 0, nullptr, nullptr, stream);
 }
 
+// Row tiles of the forward implicit GEMM for this geometry (the plan vg_conv2d_fwd runs in f32).
+static void fwd_tiles(const vg_conv_geom* g, int* bm, int* bn, int* mtiles, int* ntiles) {
+  const int M = g->N * g->Ho * g->Wo;
+  *bn = igemm_pick_bn(g->Co, VG_PREC_F32);
+  *ntiles = (g->Co + *bn - 1) / *bn;
+  *bm = igemm_pick_bm(M, *ntiles, 1, *bn, VG_PREC_F32);
+  *mtiles = (M + *bm - 1) / *bm;
+}
+
+static int conv_fwd_impl(const vg_conv_geom* g, const float* x, const float* w, const float* bias, float* y, int precision,
+                         void* workspace, size_t workspace_bytes, const void* x_planes, const void* w_planes,
+                         double* stats, int* stats_written, void* stream);
+
 extern "C" int vg_conv2d_fwd_prec(const vg_conv_geom* g, const float* x, const float* w, const float* bias,
                                   float* y, int precision, void* workspace, size_t workspace_bytes, const void* x_planes,
                                   const void* w_planes, void* stream) {
+  return conv_fwd_impl(g, x, w, bias, y, precision, workspace, workspace_bytes, x_planes, w_planes, nullptr, nullptr, stream);
+}
+
+extern "C" size_t vg_conv2d_bnstats_workspace_bytes(int mode, const vg_conv_geom* g) {
+  if (vg_check_geom(g, "vg_conv2d_bnstats_workspace_bytes") || mode < 0 || mode > 1) return 0;
+  // an upper bound that does not depend on the tile the plan picks: 64-row tiles
+  long long rows, classes = 1, cols;
+  if (mode == 0) {
+    rows = (long long)g->N * g->Ho * g->Wo;
+    cols = g->Co;
+  } else {
+    rows = (long long)g->N * ((g->H + g->sh - 1) / g->sh) * ((g->W + g->sw - 1) / g->sw);
+    classes = (long long)g->sh * g->sw;
+    cols = g->Ci;
+  }
+  const long long tiles = ((rows + 63) / 64) * classes;
+  return (size_t)(tiles * (3 * cols + 1)) * sizeof(double);
+}
+
+extern "C" int vg_conv2d_fwd_bnstats(const vg_conv_geom* g, const float* x, const float* w, const float* bias, float* y,
+                                     void* stats, size_t stats_bytes, int* stats_written, void* stream) {
+  VG_REQUIRE(stats && stats_written && vg_aligned16(stats), "vg_conv2d_fwd_bnstats: null or misaligned statistics buffer");
+  if (stats_bytes < vg_conv2d_bnstats_workspace_bytes(0, g))
+    return vg_fail(VG_ERR_WORKSPACE, "vg_conv2d_fwd_bnstats: statistics buffer of %zu bytes required, got %zu",
+                   vg_conv2d_bnstats_workspace_bytes(0, g), stats_bytes);
+  return conv_fwd_impl(g, x, w, bias, y, VG_PREC_F32, nullptr, 0, nullptr, nullptr, (double*)stats, stats_written, stream);
+}
+
+static int conv_fwd_impl(const vg_conv_geom* g, const float* x, const float* w, const float* bias, float* y, int precision,
+                         void* workspace, size_t workspace_bytes, const void* x_planes, const void* w_planes,
+                         double* stats, int* stats_written, void* stream) {
+  if (stats_written) *stats_written = 0;
   if (int e = vg_check_geom(g, "vg_conv2d_fwd")) return e;
   if (int e = check_precision(precision, "vg_conv2d_fwd")) return e;
   VG_REQUIRE(x && w && y, "vg_conv2d_fwd: null tensor pointer");
@@ -72,10 +117,40 @@ extern "C" int vg_conv2d_fwd_prec(const vg_conv_geom* g, const float* x, const f
   }
   if (igemm_set_operands(p, (long long)g->N * g->H * g->W * g->Ci, (long long)g->Co * p.Ktot))
     return vg_fail(VG_ERR_INVALID, "vg_conv2d_fwd: the MFMA kernels address operands with 31-bit byte offsets; x or w is 2 GiB or larger");
+  if (stats) {   // with column statistics where such a kernel exists for the plan, else plainly
+    p.stats = stats;
+    p.stats_tiles = p.mtiles;
+    if (igemm_launch<MODE_FWD, false>(p, bm, bn, va, vb, grid, (hipStream_t)stream, precision) == 0) {
+      VG_CHECK_LAUNCH("vg_conv2d_fwd(statistics)");
+      *stats_written = 1;
+      return VG_OK;
+    }
+    p.stats = nullptr;
+  }
   if (igemm_launch<MODE_FWD, false>(p, bm, bn, va, vb, grid, (hipStream_t)stream, precision) != 0)
     return vg_fail(VG_ERR_INVALID, "vg_conv2d_fwd: no kernel variant for bn=%d va=%d vb=%d", bn, va, vb);
   VG_CHECK_LAUNCH("vg_conv2d_fwd");
   return VG_OK;
+}
+
+// Tiles and rows of the statistics vg_conv2d_fwd_bnstats / vg_conv2d_dgrad_bnstats left for this geometry.
+void vg_bnstats_layout(int mode, const vg_conv_geom* g, int* tiles, long long* rows, int* cols) {
+  int bm, bn, mtiles, ntiles;
+  if (mode == 0) {
+    fwd_tiles(g, &bm, &bn, &mtiles, &ntiles);
+    *tiles = mtiles;
+    *rows = (long long)g->N * g->Ho * g->Wo;
+    *cols = g->Co;
+  } else {
+    const int Hc = (g->H + g->sh - 1) / g->sh, Wc = (g->W + g->sw - 1) / g->sw;
+    const int M = g->N * Hc * Wc;
+    bn = igemm_pick_bn(g->Ci, VG_PREC_F32);
+    ntiles = (g->Ci + bn - 1) / bn;
+    bm = igemm_pick_bm(M, ntiles, g->sh * g->sw, bn, VG_PREC_F32);
+    *tiles = ((M + bm - 1) / bm) * g->sh * g->sw;
+    *rows = (long long)g->N * g->H * g->W;
+    *cols = g->Ci;
+  }
 }
 
 int vg_try_fwd_stem_act(const vg_conv_geom* g, const float* x, const float* w, const float* bias, float* y, int act,

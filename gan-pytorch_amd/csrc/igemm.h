@@ -60,6 +60,8 @@ struct IgemmParams {
   int bias_mod;
   long long slab_stride;  // wgrad: elements per split-K slab
   unsigned a_bytes, b_bytes;  // sizes of A and B (below 2 GiB each: igemm_set_operands)
+  double* stats;              // STATS kernels: per-tile column statistics [tiles][3][Ncols], then [tiles] row counts
+  int stats_tiles;            // row tiles over all parity classes
 };
 
 // Operand sizes for the kernel's range-checked loads; -1 when an operand cannot be addressed with a 31-bit byte offset.
@@ -73,7 +75,10 @@ static inline int igemm_set_operands(IgemmParams& p, long long a_elems, long lon
 #define IGEMM_BK 32
 #define IGEMM_LDK 36
 
-template <int MODE, int BM, int BN, int WAVES_M, bool B_MC, int VA, int VB, int PREC = PREC_F32, int NW = 4>
+// STATS: the epilogue also leaves, per row tile and column, the statistics a BatchNorm behind the convolution needs
+// (a shift value, the sum of (y - shift) and the sum of (y - shift)^2 over the tile's valid rows, and the tile's row
+// count), so the norm does not have to read the output again to get its batch mean and variance.
+template <int MODE, int BM, int BN, int WAVES_M, bool B_MC, int VA, int VB, int PREC = PREC_F32, int NW = 4, bool STATS = false>
 // (eight-wave blocks are meant to run two to a CU, four waves per SIMD: the register allocator is told so)
 __global__ void __launch_bounds__(NW * 64, NW == 8 ? 4 : 1) igemm_kernel(const IgemmParams p) {
   constexpr int NT = NW * 64;      // threads per block
@@ -141,7 +146,12 @@ __global__ void __launch_bounds__(NW * 64, NW == 8 ? 4 : 1) igemm_kernel(const I
     M = p.N * Hc * Wc;
     Ktot = nth * ntw * p.Co;
     kend = Ktot;
-    if (m0 >= M) return;  // block-uniform
+    if (m0 >= M) {        // block-uniform
+      if constexpr (STATS) {
+        if (nt == 0 && tid == 0) p.stats[(size_t)p.stats_tiles * 3 * p.Ncols + (zz * p.mtiles + mt)] = 0.0;
+      }
+      return;
+    }
   } else if constexpr (MODE == MODE_WGRAD) {
     kbeg = zz * p.kchunk;
     kend = min(kbeg + p.kchunk, p.Ktot);
@@ -726,6 +736,57 @@ __global__ void __launch_bounds__(NW * 64, NW == 8 ? 4 : 1) igemm_kernel(const I
       for (int ni = 0; ni < TN; ++ni) asm volatile("" ::"v"(bcol[ni]));
     }
   }
+  if constexpr (STATS) {
+    // The shift is the tile's first row (always a valid one), so the sums are of deviations of the size of the spread,
+    // not of the mean; lanes add their 16 * TM rows in f32, the wave halves and the waves of a column are added in a
+    // fixed order, and the tile's three numbers per column leave as doubles.
+    const int tile = (MODE == MODE_DGRAD) ? zz * p.mtiles + mt : mt;
+    float* sh = smem;               // [BN]
+    float* part = smem + BN;        // [WAVES_M][BN][2]
+    __syncthreads();                // every wave is done with the staged tiles
+    if (wm == 0 && h == 0) {
+#pragma unroll
+      for (int ni = 0; ni < TN; ++ni) sh[(wn * TN + ni) * 32 + r] = acc[0][ni][0] + (has_bias ? bcol[ni] : 0.f);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int ni = 0; ni < TN; ++ni) {
+      const float s = sh[(wn * TN + ni) * 32 + r];
+      float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int mi = 0; mi < TM; ++mi) {
+        const int row_t = m0 + (wm * TM + mi) * 32 + 4 * h;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          if (row_t + (e & 3) + 8 * (e >> 2) < M) {
+            const float d = acc[mi][ni][e] + (has_bias ? bcol[ni] : 0.f) - s;
+            s1 += d;
+            s2 = fmaf(d, d, s2);
+          }
+        }
+      }
+      s1 += __shfl_xor(s1, 32, 64);
+      s2 += __shfl_xor(s2, 32, 64);
+      if (h == 0) {
+        part[(wm * BN + (wn * TN + ni) * 32 + r) * 2] = s1;
+        part[(wm * BN + (wn * TN + ni) * 32 + r) * 2 + 1] = s2;
+      }
+    }
+    __syncthreads();
+    if (tid < BN && n0 + tid < p.Ncols) {
+      double S1 = 0.0, S2 = 0.0;
+#pragma unroll
+      for (int w = 0; w < WAVES_M; ++w) {
+        S1 += (double)part[(w * BN + tid) * 2];
+        S2 += (double)part[(w * BN + tid) * 2 + 1];
+      }
+      double* st = p.stats + (size_t)tile * 3 * p.Ncols + n0 + tid;
+      st[0] = (double)sh[tid];
+      st[p.Ncols] = S1;
+      st[2 * (size_t)p.Ncols] = S2;
+    }
+    if (tid == 0 && nt == 0) p.stats[(size_t)p.stats_tiles * 3 * p.Ncols + tile] = (double)min(BM, M - m0);
+  }
   float* colp = outp + n0 + wn * TN * 32 + r;
   // dgrad: the rows of a tile are pixels of one parity class, scattered over the output image. Each row's element
   // offset is worked out once per block (two divisions per row) and left in LDS, which the k loop no longer needs,
@@ -795,6 +856,15 @@ static inline int igemm_launch(const IgemmParams& p, int bm, int bn, int va, int
   }
   // f32, 16-byte-vector operands: eight waves per block on the three large tiles (half the accumulators per wave, so
   // two blocks bring four waves to every SIMD instead of two; measured +2..10 % on the DCGAN layers)
+  if (igemm_waves(bm, bn, va, vb, prec) == 8 && p.stats) {
+    if constexpr (MODE != MODE_WGRAD) {
+      if (bm == 128 && bn == 128) vg_launch_timed(igemm_kernel<MODE, 128, 128, 2, B_MC, 4, 4, PREC_F32, 8, true>, grid, dim3(512), 0, st, p);
+      else if (bm == 128) vg_launch_timed(igemm_kernel<MODE, 128, 64, 4, B_MC, 4, 4, PREC_F32, 8, true>, grid, dim3(512), 0, st, p);
+      else vg_launch_timed(igemm_kernel<MODE, 64, 128, 2, B_MC, 4, 4, PREC_F32, 8, true>, grid, dim3(512), 0, st, p);
+      return 0;
+    }
+  }
+  if (p.stats) return -3;    // column statistics exist for the eight-wave f32 kernels only: the caller runs without them
   if (igemm_waves(bm, bn, va, vb, prec) == 8) {
     if (bm == 128 && bn == 128) vg_launch_timed(igemm_kernel<MODE, 128, 128, 2, B_MC, 4, 4, PREC_F32, 8>, grid, dim3(512), 0, st, p);
     else if (bm == 128) vg_launch_timed(igemm_kernel<MODE, 128, 64, 4, B_MC, 4, 4, PREC_F32, 8>, grid, dim3(512), 0, st, p);

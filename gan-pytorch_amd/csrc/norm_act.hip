@@ -303,9 +303,13 @@ struct BnFinalizeE {
   __device__ void operator()(int c, const double (&s)[NV]) const {
     const double n = (double)M;
     const double s1 = s[0] / n;
-    double var = s[1] / n - s1 * s1;
+    finish(c, (double)x[c] + s1, s[1] / n - s1 * s1);
+  }
+  // mean and biased variance of column c (in double) -> the norm's statistics and running statistics
+  __device__ void finish(int c, double mean_d, double var) const {
+    const double n = (double)M;
     var = var < 0.0 ? 0.0 : var;
-    const float mu = (float)((double)x[c] + s1);
+    const float mu = (float)mean_d;
     const float varf = (float)var;
     mean[c] = mu;
     invstd[c] = 1.0f / sqrtf(varf + eps);
@@ -317,6 +321,70 @@ struct BnFinalizeE {
     if (num_batches_tracked && c == 0) *num_batches_tracked += 1;
   }
 };
+
+// Batch statistics from the per-tile column statistics a convolution's epilogue left (igemm.h, STATS): tile t holds,
+// per column, a shift s_t, S1_t = sum (y - s_t) and S2_t = sum (y - s_t)^2 over its n_t rows. Against the reference
+// shift s_0 of the first tile: sum (y - s_0) = sum_t [S1_t + n_t d_t] and sum (y - s_0)^2 = sum_t [S2_t + 2 d_t S1_t +
+// n_t d_t^2] with d_t = s_t - s_0, added in double (s_0 is a value of the column, so the two sums are of the size of
+// the spread and their combination into the variance does not cancel). One pass, 4 columns x 256 tile lanes per block,
+// four tiles in flight per lane, lanes added in a fixed tree. Same epilogue as the moments reduction (mean, invstd,
+// running statistics, batch counter).
+__global__ void __launch_bounds__(1024) bn_tiles_final_kernel(const double* __restrict__ stats, int tiles, int C, double n_rows,
+                                                              BnFinalizeE fin) {
+  constexpr int COLS = 4, LANES = 1024 / COLS;      // few columns per block: a 64-channel layer still gets 16 blocks
+  __shared__ double red[2][1024];
+  const int cl = threadIdx.x % COLS, q = threadIdx.x / COLS;
+  const int c = blockIdx.x * COLS + cl;
+  const double* counts = stats + (size_t)tiles * 3 * C;
+  double a = 0.0, b = 0.0, s0 = 0.0;
+  if (c < C) {
+    s0 = stats[c];
+    int t = q;
+    for (; t + 3 * LANES < tiles; t += 4 * LANES) {
+      double n[4], s[4], s1[4], s2[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const size_t base = ((size_t)(t + LANES * u) * 3) * C + c;
+        n[u] = counts[t + LANES * u];
+        s[u] = stats[base];
+        s1[u] = stats[base + C];
+        s2[u] = stats[base + 2 * (size_t)C];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (n[u] > 0.0) {
+          const double d = s[u] - s0;
+          a += s1[u] + n[u] * d;
+          b += s2[u] + 2.0 * d * s1[u] + n[u] * d * d;
+        }
+      }
+    }
+    for (; t < tiles; t += LANES) {
+      const double n = counts[t];
+      if (n > 0.0) {
+        const size_t base = ((size_t)t * 3) * C + c;
+        const double d = stats[base] - s0, s1 = stats[base + C];
+        a += s1 + n * d;
+        b += stats[base + 2 * (size_t)C] + 2.0 * d * s1 + n * d * d;
+      }
+    }
+  }
+  // lanes of a column added pairwise in a fixed tree (LDS), then the column's result
+  red[0][threadIdx.x] = a;
+  red[1][threadIdx.x] = b;
+  __syncthreads();
+  for (int half = LANES / 2; half > 0; half >>= 1) {
+    if (q < half) {
+      red[0][threadIdx.x] += red[0][threadIdx.x + half * COLS];
+      red[1][threadIdx.x] += red[1][threadIdx.x + half * COLS];
+    }
+    __syncthreads();
+  }
+  if (q == 0 && c < C) {
+    const double m1 = red[0][cl] / n_rows;
+    fin.finish(c, s0 + m1, red[1][cl] / n_rows - m1 * m1);
+  }
+}
 
 __global__ void __launch_bounds__(256) invstd_kernel(const float* var, float* invstd, int C, float eps) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
@@ -576,6 +644,23 @@ extern "C" int vg_bn_stats(const float* x, int M, int C, float eps, float moment
   ShiftedMomentsF f{x};
   BnFinalizeE fin{x, M, eps, momentum, mean, invstd, running_mean, running_var, num_batches_tracked};
   return run_colreduce_with<2>("vg_bn_stats", f, M, C, all_aligned({x}), fin, ws, ws_bytes, (hipStream_t)stream);
+}
+
+void vg_bnstats_layout(int mode, const vg_conv_geom* g, int* tiles, long long* rows, int* cols);
+
+extern "C" int vg_bn_stats_from_conv(int mode, const vg_conv_geom* g, const void* stats, float eps, float momentum,
+                                     float* mean, float* invstd, float* running_mean, float* running_var,
+                                     long long* num_batches_tracked, void* stream) {
+  VG_REQUIRE(g && stats && mean && invstd && (mode == 0 || mode == 1), "vg_bn_stats_from_conv: bad arguments");
+  int tiles, C;
+  long long rows;
+  vg_bnstats_layout(mode, g, &tiles, &rows, &C);
+  VG_REQUIRE(rows > 0 && rows < (1LL << 31), "vg_bn_stats_from_conv: bad geometry");
+  BnFinalizeE fin{nullptr, (int)rows, eps, momentum, mean, invstd, running_mean, running_var, num_batches_tracked};
+  hipLaunchKernelGGL(bn_tiles_final_kernel, dim3((C + 3) / 4), dim3(1024), 0, (hipStream_t)stream, (const double*)stats, tiles,
+                     C, (double)rows, fin);
+  VG_CHECK_LAUNCH("vg_bn_stats_from_conv");
+  return VG_OK;
 }
 
 extern "C" int vg_bn_invstd_from_var(const float* var, float* invstd, int C, float eps, void* stream) {

@@ -84,6 +84,10 @@ SIGNATURES = {
     "vg_bn_workspace_bytes": (c_size_t, [c_int, c_int]),
     "vg_bn_stats": (c_int, [_P, c_int, c_int, c_float, c_float, _P, _P, _P, _P, _P, _P, c_size_t, _P]),
     "vg_bn_invstd_from_var": (c_int, [_P, _P, c_int, c_float, _P]),
+    "vg_conv2d_bnstats_workspace_bytes": (c_size_t, [c_int, _P]),
+    "vg_conv2d_fwd_bnstats": (c_int, [_P, _P, _P, _P, _P, _P, c_size_t, _P, _P]),
+    "vg_conv2d_dgrad_bnstats": (c_int, [_P, _P, _P, _P, _P, _P, c_size_t, _P, _P]),
+    "vg_bn_stats_from_conv": (c_int, [c_int, _P, _P, c_float, c_float, _P, _P, _P, _P, _P, _P]),
     "vg_bn_apply": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_float, _P]),
     "vg_bn_bwd_reduce": (c_int, [_P, _P, _P, _P, c_int, c_int, _P, _P, c_size_t, _P, c_int, c_float, _P, _P, _P]),
     "vg_bn_bwd_apply": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, c_int, _P, c_int, c_float, _P, _P]),

@@ -121,6 +121,12 @@ def _fused_act(norm, act):
     return None
 
 
+def _wants_stats(conv, norm):
+    """A training-mode BatchNorm2d directly behind a (transposed) convolution, neither with hooks."""
+    return (isinstance(conv, (HipConv2d, HipConvTranspose2d)) and type(norm) is HipBatchNorm2d and norm.training
+            and not _has_hooks(conv) and not _has_hooks(norm))
+
+
 class HipSequential(nn.Sequential):
     """nn.Sequential that runs a BatchNorm (or, where the library has a fused kernel, a convolution) followed by
     ReLU / LeakyReLU as one fused operator: the
@@ -133,6 +139,13 @@ class HipSequential(nn.Sequential):
         while i < n:
             m = mods[i]
             fused = _fused_act(m, mods[i + 1]) if i + 1 < n else None
+            if i + 1 < n and _wants_stats(m, mods[i + 1]):
+                # the norm behind this convolution takes its batch statistics from the convolution's epilogue
+                ops.norm_stats.request()
+                x = m(x)
+                ops.norm_stats.cancel()
+                i += 1
+                continue
             if fused is not None:
                 x = m(x, fused[0], fused[1])
                 i += 2

@@ -309,12 +309,68 @@ class _PlaneCache:
 plane_cache = _PlaneCache()
 
 
+class _NormStats:
+    """Hand-over of batch statistics from a convolution to the BatchNorm directly behind it. The container that runs
+    the two layers (modules.HipSequential) asks for it with `request()` right before it calls the convolution; the
+    convolution's epilogue then leaves per-tile column statistics beside its output (f32 MFMA tiles only; other
+    kernels and precisions ignore the request), and the norm, finding statistics that belong to its input tensor, merges
+    them instead of reading the whole activation again. One-shot in both directions."""
+
+    def __init__(self):
+        self.wanted = False
+        self.ready = None       # (data_ptr of the output, mode, geometry, statistics buffer)
+
+    def request(self):
+        self.wanted = True
+        self.ready = None
+
+    def cancel(self):
+        self.wanted = False
+
+    def take_request(self):
+        wanted, self.wanted = self.wanted, False
+        return wanted and _precision == 0
+
+    def offer(self, y, mode, g, stats):
+        self.ready = (y.data_ptr(), mode, g, stats)
+
+    def claim(self, x, m, c):
+        """The statistics left for activation `x` viewed as [m][c], or None."""
+        ready, self.ready = self.ready, None
+        if ready is None or ready[0] != x.data_ptr():
+            return None
+        mode, g = ready[1], ready[2]
+        rows, cols = (g.N * g.Ho * g.Wo, g.Co) if mode == 0 else (g.N * g.H * g.W, g.Ci)
+        return ready if (rows, cols) == (m, c) else None
+
+
+norm_stats = _NormStats()
+
+
+def _conv_with_stats(mode, g, args, out):
+    """Run the convolution through the entry point that also leaves column statistics; True when it did."""
+    lib = _hip.load()
+    nbytes = lib.vg_conv2d_bnstats_workspace_bytes(mode, ctypes.byref(g.c))
+    if not nbytes:
+        return False
+    stats = torch.empty(nbytes, dtype=torch.uint8, device=out.device)
+    written = ctypes.c_int(0)
+    name = "vg_conv2d_fwd_bnstats" if mode == 0 else "vg_conv2d_dgrad_bnstats"
+    _launch_conv(mode, g, lambda: call(name, ctypes.byref(g.c), *args, _ptr(out), ctypes.c_void_p(stats.data_ptr()),
+                                       c_size_t(nbytes), ctypes.byref(written), _stream()))
+    if written.value:
+        norm_stats.offer(out, mode, g, stats)
+    return True
+
+
 def raw_conv_fwd(g, x, w, bias):
     x, w = to_nhwc(x), _weight_mem(w)
     _check_shape(x, g.x_shape(), "conv input")
     if w.numel() != g.w_numel():
         raise _hip.HipError("weight has %d elements, geometry expects %d" % (w.numel(), g.w_numel()))
     y = _new_act(g.N, g.Co, g.Ho, g.Wo, x, g.flat)
+    if norm_stats.take_request() and _conv_with_stats(0, g, (_ptr(x), _ptr(w), _ptr(bias)), y):
+        return y
     nbytes, wsp = _conv_workspace(0, g, x.device)
     xp, wp = plane_cache.pointer(0, g, x), plane_cache.pointer(0, g, w)
     _launch_conv(0, g, lambda: call("vg_conv2d_fwd_prec", ctypes.byref(g.c), _ptr(x), _ptr(w), _ptr(bias), _ptr(y),
@@ -328,6 +384,8 @@ def raw_conv_dgrad(g, gy, w, bias):
     if w.numel() != g.w_numel():
         raise _hip.HipError("weight has %d elements, geometry expects %d" % (w.numel(), g.w_numel()))
     gx = _new_act(g.N, g.Ci, g.H, g.W, gy, g.flat)
+    if norm_stats.take_request() and _conv_with_stats(1, g, (_ptr(gy), _ptr(w), _ptr(bias)), gx):
+        return gx
     nbytes, wsp = _conv_workspace(1, g, gy.device)
     gp, wp = plane_cache.pointer(1, g, gy), plane_cache.pointer(1, g, w)
     _launch_conv(1, g, lambda: call("vg_conv2d_dgrad_prec", ctypes.byref(g.c), _ptr(gy), _ptr(w), _ptr(bias), _ptr(gx),
@@ -598,11 +656,17 @@ class BatchNormTrainFn(Function):
         ws, nbytes = _bn_ws(m, c, x.device)
         # the running statistics are updated once per pass, in program order, also when the passes of a sub-step run
         # on different streams
+        counter = ctypes.c_void_p(batches_tracked.data_ptr()) if batches_tracked is not None else None
+        left = norm_stats.claim(x, m, c)
         with streams.ordered_write(running_mean):
-            call("vg_bn_stats", _ptr(x), m, c, c_float(eps), c_float(momentum), _ptr(mean), _ptr(invstd),
-                 _ptr(running_mean), _ptr(running_var),
-                 ctypes.c_void_p(batches_tracked.data_ptr()) if batches_tracked is not None else None,
-                 ctypes.c_void_p(ws.data_ptr()), c_size_t(nbytes), _stream())
+            if left is not None:      # the convolution in front left per-tile statistics: merge them
+                call("vg_bn_stats_from_conv", left[1], ctypes.byref(left[2].c), ctypes.c_void_p(left[3].data_ptr()),
+                     c_float(eps), c_float(momentum), _ptr(mean), _ptr(invstd), _ptr(running_mean), _ptr(running_var),
+                     counter, _stream())
+            else:
+                call("vg_bn_stats", _ptr(x), m, c, c_float(eps), c_float(momentum), _ptr(mean), _ptr(invstd),
+                     _ptr(running_mean), _ptr(running_var), counter,
+                     ctypes.c_void_p(ws.data_ptr()), c_size_t(nbytes), _stream())
         y = torch.empty_like(x)
         call("vg_bn_apply", _ptr(x), _ptr(mean), _ptr(invstd), _ptr(gamma), _ptr(beta), _ptr(y), m, c,
              act, c_float(slope), _stream())

@@ -192,6 +192,23 @@ size_t vg_bn_workspace_bytes(int M, int C);
 int vg_bn_stats(const float* x, int M, int C, float eps, float momentum, float* mean, float* invstd,
                 float* running_mean, float* running_var, long long* num_batches_tracked, void* workspace,
                 size_t workspace_bytes, void* stream);
+/* Batch statistics without a pass over the activation: a convolution (mode 0: vg_conv2d_fwd_bnstats) or transposed
+ * convolution (mode 1: vg_conv2d_dgrad_bnstats) that feeds a BatchNorm leaves, per row tile of its output and per
+ * channel, a shift, the sum of (y - shift), the sum of (y - shift)^2 and the tile's row count in `stats`
+ * (vg_conv2d_bnstats_workspace_bytes(mode, g) bytes, 16-byte aligned); vg_bn_stats_from_conv merges the tiles (in
+ * double, fixed order) into what vg_bn_stats computes: mean, invstd, running statistics, batch counter. The convolution
+ * entry points compute exactly what vg_conv2d_fwd / vg_conv2d_dgrad compute; *stats_written is 1 when the geometry ran
+ * on a kernel that leaves the statistics (the eight-wave f32 MFMA tiles) and 0 when it did not (thin, stem and small
+ * shapes: the caller then uses vg_bn_stats). Reference: nn.BatchNorm2d behind nn.Conv2d / nn.ConvTranspose2d in the
+ * user networks (examples/example_input_formats.py:52-77). */
+size_t vg_conv2d_bnstats_workspace_bytes(int mode, const vg_conv_geom* g);
+int vg_conv2d_fwd_bnstats(const vg_conv_geom* g, const float* x, const float* w, const float* bias, float* y,
+                          void* stats, size_t stats_bytes, int* stats_written, void* stream);
+int vg_conv2d_dgrad_bnstats(const vg_conv_geom* g, const float* gy, const float* w, const float* bias, float* gx,
+                            void* stats, size_t stats_bytes, int* stats_written, void* stream);
+int vg_bn_stats_from_conv(int mode, const vg_conv_geom* g, const void* stats, float eps, float momentum,
+                          float* mean, float* invstd, float* running_mean, float* running_var,
+                          long long* num_batches_tracked, void* stream);
 /* invstd[c] = 1/sqrt(var[c] + eps) (eval mode uses the running statistics) */
 int vg_bn_invstd_from_var(const float* var, float* invstd, int C, float eps, void* stream);
 /* y = act((x - mean) * invstd * gamma + beta); gamma/beta nullable (affine=False) */

@@ -804,3 +804,57 @@ def test_bn_backward_mask_rebuilt_from_input_equals_mask_from_output(gpu, act, s
         assert torch.equal(a, b), (name, int((a != b).sum()), float((a - b).abs().max()))
     # the constructed rows do sit on the kink: tiny pre-activations of both signs
     assert float(y[:3].abs().max()) < 1e-4 and bool((y[:3] > 0).any()) and bool((y[:3] <= 0).any())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind,shape,served_by_epilogue", [
+    ("conv", (64, 16, 16, 64, 128, 4, 2, 1), True),       # 64-row tiles, 128 columns
+    ("conv", (5, 17, 13, 32, 96, 3, 1, 1), True),         # ragged last row tile, 96 of 128 columns
+    ("conv", (16, 8, 8, 128, 256, 4, 2, 1), True),        # two column tiles
+    ("conv", (160, 32, 32, 32, 128, 4, 2, 1), True),      # 128-row tiles (320 of them)
+    ("conv", (4, 9, 9, 8, 16, 3, 1, 1), False),           # a shape the statistics kernels do not serve: separate pass
+    ("convT", (32, 8, 8, 256, 128, 4, 2, 1), True),       # transposed: four parity classes, 64-row tiles
+    ("convT", (16, 25, 24, 64, 64, 4, 2, 1), True),       # transposed, 128 x 64 tiles, ragged last tile of every class
+    ("convT", (3, 5, 7, 64, 64, 4, 2, 1), False),         # transposed, too small for the eight-wave tiles
+    ("convT", (40, 16, 16, 128, 128, 3, 1, 1), True),     # transposed, stride 1: a single class
+])
+def test_batch_statistics_from_the_convolution_epilogue(gpu, kind, shape, served_by_epilogue):
+    """A (transposed) convolution followed by a training-mode BatchNorm inside a Sequential: the norm takes its batch
+    statistics from per-tile sums the convolution's epilogue leaves. Mean, inverse std, running statistics and the
+    output must agree with the separate statistics pass to rounding (5e-6 of scale), and both with torch."""
+    from torch import nn
+    from vegans.engine import modules, ops
+    N, H, W, Ci, Co, k, s, p = shape
+    torch.manual_seed(7)
+    conv = nn.Conv2d(Ci, Co, k, s, p, bias=True) if kind == "conv" else nn.ConvTranspose2d(Ci, Co, k, s, p, bias=True)
+    ref = nn.Sequential(conv, nn.BatchNorm2d(Co), nn.LeakyReLU(0.2))
+    with torch.no_grad():
+        conv.bias.add_(3.0)                      # a mean well away from zero: the shifted sums must cope
+    x = torch.randn(N, Ci, H, W)
+    want = ref(x)
+    outs = {}
+    for fused in (True, False):
+        import copy
+        net = copy.deepcopy(ref)
+        net[1].reset_running_stats()
+        net = net.to("cuda")
+        modules.bind(net)
+        modules.prepare_parameters(net)
+        net.train()
+        seen = []
+        orig = ops.norm_stats.claim
+        ops.norm_stats.claim = (lambda *a, orig=orig, seen=seen: seen.append(orig(*a)) or seen[-1]) if fused else (lambda *a: None)
+        try:
+            y = net(x.to("cuda"))
+        finally:
+            ops.norm_stats.claim = orig
+        outs[fused] = (y.detach().cpu(), net[1].running_mean.cpu(), net[1].running_var.cpu(), int(net[1].num_batches_tracked))
+        if fused:
+            served = seen and seen[0] is not None
+    assert bool(served) == served_by_epilogue, (served, shape)
+    for a, b in zip(outs[True][:3], outs[False][:3]):
+        _close(a, b, 5e-6, "fused statistics vs separate pass")
+    assert outs[True][3] == outs[False][3] == 1
+    _close(outs[True][0], want, 2e-5, "conv + batch norm output vs torch")
+    _close(outs[True][1], ref[1].running_mean, 2e-5, "running mean vs torch")
+    _close(outs[True][2], ref[1].running_var, 2e-5, "running var vs torch")
