@@ -86,6 +86,10 @@ def measured_traffic(kernel):
     for name, entry in kernels.items():
         if kernel in name:
             return entry["hbm_bytes_per_launch"]
+    stem = kernel.rsplit(",", 1)[0]           # summaries made before the kernel got its last template argument
+    for name, entry in kernels.items():
+        if stem in name:
+            return entry["hbm_bytes_per_launch"]
     return None
 
 
