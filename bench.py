@@ -157,8 +157,8 @@ def main():
     # Set-up, like building the model: the first iterations of a given shape run eagerly and the third records the HIP
     # graphs that later iterations replay (data-parallel runs: a chain of graphs with the gradient all-reduces in
     # between); then the warm-up iterations, all inside one untimed `fit` call.
-    fit_quietly(host_batches(SETUP_STEPS + args.warmup))
-    X_timed = host_batches(args.steps)
+    X_timed = host_batches(args.steps)              # made ahead of the warm-up, so the GPU does not sit idle for the
+    fit_quietly(host_batches(SETUP_STEPS + args.warmup))   # time it takes to assemble it right before the timed region
     replayed = graph.replays(model)
     fence()
     t0 = time.perf_counter()
