@@ -14,13 +14,15 @@ extern "C" int vg_conv2d_dgrad(const vg_conv_geom* g, const float* gy, const flo
 
 static int conv_dgrad_impl(const vg_conv_geom* g, const float* gy, const float* w, const float* bias, float* gx,
                            int precision, void* workspace, size_t workspace_bytes, const void* gy_planes,
-                           const void* w_planes, double* stats, int* stats_written, void* stream);
+                           const void* w_planes, double* stats, int* stats_written, const VgNormBwdSrc* nb, void* stream);
+int vg_check_norm_bwd_src(const VgNormBwdSrc* nb, const void* stats, size_t stats_bytes, size_t need, const int* written,
+                          const char* who);
 
 extern "C" int vg_conv2d_dgrad_prec(const vg_conv_geom* g, const float* gy, const float* w, const float* bias,
                                     float* gx, int precision, void* workspace, size_t workspace_bytes, const void* gy_planes,
                                     const void* w_planes, void* stream) {
   return conv_dgrad_impl(g, gy, w, bias, gx, precision, workspace, workspace_bytes, gy_planes, w_planes, nullptr, nullptr,
-                         stream);
+                         nullptr, stream);
 }
 
 extern "C" int vg_conv2d_dgrad_bnstats(const vg_conv_geom* g, const float* gy, const float* w, const float* bias, float* gx,
@@ -29,12 +31,23 @@ extern "C" int vg_conv2d_dgrad_bnstats(const vg_conv_geom* g, const float* gy, c
   if (stats_bytes < vg_conv2d_bnstats_workspace_bytes(1, g))
     return vg_fail(VG_ERR_WORKSPACE, "vg_conv2d_dgrad_bnstats: statistics buffer of %zu bytes required, got %zu",
                    vg_conv2d_bnstats_workspace_bytes(1, g), stats_bytes);
-  return conv_dgrad_impl(g, gy, w, bias, gx, VG_PREC_F32, nullptr, 0, nullptr, nullptr, (double*)stats, stats_written, stream);
+  return conv_dgrad_impl(g, gy, w, bias, gx, VG_PREC_F32, nullptr, 0, nullptr, nullptr, (double*)stats, stats_written, nullptr, stream);
+}
+
+extern "C" int vg_conv2d_dgrad_bnbwd(const vg_conv_geom* g, const float* gy, const float* w, const float* bias, float* gx,
+                                     const float* bn_x, const float* bn_mean, const float* bn_invstd, const float* bn_gamma,
+                                     const float* bn_beta, int act, float slope, void* sums, size_t sums_bytes,
+                                     int* sums_written, void* stream) {
+  const VgNormBwdSrc nb{bn_x, bn_mean, bn_invstd, bn_gamma, bn_beta, act, slope};
+  if (int e = vg_check_norm_bwd_src(&nb, sums, sums_bytes, vg_conv2d_bnstats_workspace_bytes(1, g), sums_written,
+                                    "vg_conv2d_dgrad_bnbwd"))
+    return e;
+  return conv_dgrad_impl(g, gy, w, bias, gx, VG_PREC_F32, nullptr, 0, nullptr, nullptr, (double*)sums, sums_written, &nb, stream);
 }
 
 static int conv_dgrad_impl(const vg_conv_geom* g, const float* gy, const float* w, const float* bias, float* gx,
                            int precision, void* workspace, size_t workspace_bytes, const void* gy_planes,
-                           const void* w_planes, double* stats, int* stats_written, void* stream) {
+                           const void* w_planes, double* stats, int* stats_written, const VgNormBwdSrc* nb, void* stream) {
   if (stats_written) *stats_written = 0;
   if (int e = vg_check_geom(g, "vg_conv2d_dgrad")) return e;
   if (precision < VG_PREC_F32 || precision > VG_PREC_F32_SPLIT)
@@ -85,12 +98,14 @@ static int conv_dgrad_impl(const vg_conv_geom* g, const float* gy, const float* 
   if (stats) {   // with column statistics where such a kernel exists for the plan, else plainly
     p.stats = stats;
     p.stats_tiles = p.mtiles * g->sh * g->sw;
+    if (nb) igemm_set_norm_bwd(p, *nb);
     if (igemm_launch<MODE_DGRAD, true>(p, bm, bn, va, vb, grid, (hipStream_t)stream, precision) == 0) {
       VG_CHECK_LAUNCH("vg_conv2d_dgrad(statistics)");
       *stats_written = 1;
       return VG_OK;
     }
     p.stats = nullptr;
+    p.bx = nullptr;
   }
   if (igemm_launch<MODE_DGRAD, true>(p, bm, bn, va, vb, grid, (hipStream_t)stream, precision) != 0)
     return vg_fail(VG_ERR_INVALID, "vg_conv2d_dgrad: no kernel variant for bn=%d va=%d vb=%d", bn, va, vb);

@@ -43,12 +43,12 @@ static void fwd_tiles(const vg_conv_geom* g, int* bm, int* bn, int* mtiles, int*
 
 static int conv_fwd_impl(const vg_conv_geom* g, const float* x, const float* w, const float* bias, float* y, int precision,
                          void* workspace, size_t workspace_bytes, const void* x_planes, const void* w_planes,
-                         double* stats, int* stats_written, void* stream);
+                         double* stats, int* stats_written, const VgNormBwdSrc* nb, void* stream);
 
 extern "C" int vg_conv2d_fwd_prec(const vg_conv_geom* g, const float* x, const float* w, const float* bias,
                                   float* y, int precision, void* workspace, size_t workspace_bytes, const void* x_planes,
                                   const void* w_planes, void* stream) {
-  return conv_fwd_impl(g, x, w, bias, y, precision, workspace, workspace_bytes, x_planes, w_planes, nullptr, nullptr, stream);
+  return conv_fwd_impl(g, x, w, bias, y, precision, workspace, workspace_bytes, x_planes, w_planes, nullptr, nullptr, nullptr, stream);
 }
 
 extern "C" size_t vg_conv2d_bnstats_workspace_bytes(int mode, const vg_conv_geom* g) {
@@ -73,12 +73,34 @@ extern "C" int vg_conv2d_fwd_bnstats(const vg_conv_geom* g, const float* x, cons
   if (stats_bytes < vg_conv2d_bnstats_workspace_bytes(0, g))
     return vg_fail(VG_ERR_WORKSPACE, "vg_conv2d_fwd_bnstats: statistics buffer of %zu bytes required, got %zu",
                    vg_conv2d_bnstats_workspace_bytes(0, g), stats_bytes);
-  return conv_fwd_impl(g, x, w, bias, y, VG_PREC_F32, nullptr, 0, nullptr, nullptr, (double*)stats, stats_written, stream);
+  return conv_fwd_impl(g, x, w, bias, y, VG_PREC_F32, nullptr, 0, nullptr, nullptr, (double*)stats, stats_written, nullptr, stream);
+}
+
+int vg_check_norm_bwd_src(const VgNormBwdSrc* nb, const void* stats, size_t stats_bytes, size_t need, const int* written,
+                          const char* who) {
+  VG_REQUIRE(stats && written && vg_aligned16(stats), "%s: null or misaligned buffer for the per-tile sums", who);
+  VG_REQUIRE(nb->x && nb->mean && nb->invstd, "%s: the norm's input and batch statistics are required", who);
+  VG_REQUIRE(nb->act == VG_ACT_NONE || nb->act == VG_ACT_RELU || nb->act == VG_ACT_LRELU,
+             "%s: only ReLU / LeakyReLU can sit between the norm and the convolution", who);
+  if (stats_bytes < need)
+    return vg_fail(VG_ERR_WORKSPACE, "%s: buffer of %zu bytes required for the per-tile sums, got %zu", who, need, stats_bytes);
+  return VG_OK;
+}
+
+extern "C" int vg_conv2d_fwd_bnbwd(const vg_conv_geom* g, const float* x, const float* w, const float* bias, float* y,
+                                   const float* bn_x, const float* bn_mean, const float* bn_invstd, const float* bn_gamma,
+                                   const float* bn_beta, int act, float slope, void* sums, size_t sums_bytes,
+                                   int* sums_written, void* stream) {
+  const VgNormBwdSrc nb{bn_x, bn_mean, bn_invstd, bn_gamma, bn_beta, act, slope};
+  if (int e = vg_check_norm_bwd_src(&nb, sums, sums_bytes, vg_conv2d_bnstats_workspace_bytes(0, g), sums_written,
+                                    "vg_conv2d_fwd_bnbwd"))
+    return e;
+  return conv_fwd_impl(g, x, w, bias, y, VG_PREC_F32, nullptr, 0, nullptr, nullptr, (double*)sums, sums_written, &nb, stream);
 }
 
 static int conv_fwd_impl(const vg_conv_geom* g, const float* x, const float* w, const float* bias, float* y, int precision,
                          void* workspace, size_t workspace_bytes, const void* x_planes, const void* w_planes,
-                         double* stats, int* stats_written, void* stream) {
+                         double* stats, int* stats_written, const VgNormBwdSrc* nb, void* stream) {
   if (stats_written) *stats_written = 0;
   if (int e = vg_check_geom(g, "vg_conv2d_fwd")) return e;
   if (int e = check_precision(precision, "vg_conv2d_fwd")) return e;
@@ -120,12 +142,14 @@ static int conv_fwd_impl(const vg_conv_geom* g, const float* x, const float* w, 
   if (stats) {   // with column statistics where such a kernel exists for the plan, else plainly
     p.stats = stats;
     p.stats_tiles = p.mtiles;
+    if (nb) igemm_set_norm_bwd(p, *nb);
     if (igemm_launch<MODE_FWD, false>(p, bm, bn, va, vb, grid, (hipStream_t)stream, precision) == 0) {
       VG_CHECK_LAUNCH("vg_conv2d_fwd(statistics)");
       *stats_written = 1;
       return VG_OK;
     }
     p.stats = nullptr;
+    p.bx = nullptr;
   }
   if (igemm_launch<MODE_FWD, false>(p, bm, bn, va, vb, grid, (hipStream_t)stream, precision) != 0)
     return vg_fail(VG_ERR_INVALID, "vg_conv2d_fwd: no kernel variant for bn=%d va=%d vb=%d", bn, va, vb);
@@ -248,7 +272,7 @@ extern "C" int vg_conv2d_variant(int mode, const vg_conv_geom* g, char* buf, siz
   const int nw = igemm_waves(bm, bn, va, vb, PREC_F32);
   // (last argument: the variant without column statistics; a convolution asked to leave BatchNorm statistics runs the
   // instance that ends in "true")
-  snprintf(buf, len, "igemm_kernel<%d, %d, %d, %d, %s, %d, %d, 0, %d, false>", kmode, bm, bn, igemm_waves_m(bm, bn, nw),
+  snprintf(buf, len, "igemm_kernel<%d, %d, %d, %d, %s, %d, %d, 0, %d, 0>", kmode, bm, bn, igemm_waves_m(bm, bn, nw),
            bmc ? "true" : "false", va, vb, nw);
   return VG_OK;
 }

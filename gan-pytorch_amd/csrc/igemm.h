@@ -60,8 +60,13 @@ struct IgemmParams {
   int bias_mod;
   long long slab_stride;  // wgrad: elements per split-K slab
   unsigned a_bytes, b_bytes;  // sizes of A and B (below 2 GiB each: igemm_set_operands)
-  double* stats;              // STATS kernels: per-tile column statistics [tiles][3][Ncols], then [tiles] row counts
+  double* stats;              // STATS kernels: per-tile column statistics [tiles][3 or 2][Ncols], then [tiles] row counts
   int stats_tiles;            // row tiles over all parity classes
+  // STATS == 2: the output is the gradient arriving at a BatchNorm's output; bx is that norm's input (laid out like
+  // the output), the rest its statistics, affine parameters and fused activation
+  const float *bx, *bmean, *binvstd, *bgamma, *bbeta;
+  int bact;
+  float bslope;
 };
 
 // Operand sizes for the kernel's range-checked loads; -1 when an operand cannot be addressed with a 31-bit byte offset.
@@ -75,10 +80,13 @@ static inline int igemm_set_operands(IgemmParams& p, long long a_elems, long lon
 #define IGEMM_BK 32
 #define IGEMM_LDK 36
 
-// STATS: the epilogue also leaves, per row tile and column, the statistics a BatchNorm behind the convolution needs
+// STATS = 1: the epilogue also leaves, per row tile and column, the statistics a BatchNorm behind the convolution needs
 // (a shift value, the sum of (y - shift) and the sum of (y - shift)^2 over the tile's valid rows, and the tile's row
 // count), so the norm does not have to read the output again to get its batch mean and variance.
-template <int MODE, int BM, int BN, int WAVES_M, bool B_MC, int VA, int VB, int PREC = PREC_F32, int NW = 4, bool STATS = false>
+// STATS = 2: the output is the gradient g arriving at the output of a BatchNorm (+ ReLU / LeakyReLU) whose input x is
+// at hand: the epilogue leaves, per row tile and column, sum (g m) and sum (g m xhat) (m the activation's slope mask,
+// xhat the normalised input), the two sums that norm's backward pass needs before it can form its input gradient.
+template <int MODE, int BM, int BN, int WAVES_M, bool B_MC, int VA, int VB, int PREC = PREC_F32, int NW = 4, int STATS = 0>
 // (eight-wave blocks are meant to run two to a CU, four waves per SIMD: the register allocator is told so)
 __global__ void __launch_bounds__(NW * 64, NW == 8 ? 4 : 1) igemm_kernel(const IgemmParams p) {
   constexpr int NT = NW * 64;      // threads per block
@@ -147,8 +155,9 @@ __global__ void __launch_bounds__(NW * 64, NW == 8 ? 4 : 1) igemm_kernel(const I
     Ktot = nth * ntw * p.Co;
     kend = Ktot;
     if (m0 >= M) {        // block-uniform
-      if constexpr (STATS) {
-        if (nt == 0 && tid == 0) p.stats[(size_t)p.stats_tiles * 3 * p.Ncols + (zz * p.mtiles + mt)] = 0.0;
+      if constexpr (STATS != 0) {
+        constexpr int NQ = STATS == 1 ? 3 : 2;
+        if (nt == 0 && tid == 0) p.stats[(size_t)p.stats_tiles * NQ * p.Ncols + (zz * p.mtiles + mt)] = 0.0;
       }
       return;
     }
@@ -736,7 +745,7 @@ __global__ void __launch_bounds__(NW * 64, NW == 8 ? 4 : 1) igemm_kernel(const I
       for (int ni = 0; ni < TN; ++ni) asm volatile("" ::"v"(bcol[ni]));
     }
   }
-  if constexpr (STATS) {
+  if constexpr (STATS == 1) {
     // The shift is the tile's first row (always a valid one), so the sums are of deviations of the size of the spread,
     // not of the mean; lanes add their 16 * TM rows in f32, the wave halves and the waves of a column are added in a
     // fixed order, and the tile's three numbers per column leave as doubles.
@@ -807,6 +816,86 @@ __global__ void __launch_bounds__(NW * 64, NW == 8 ? 4 : 1) igemm_kernel(const I
     }
     __syncthreads();
   }
+  if constexpr (STATS == 2) {
+    const int tile = (MODE == MODE_DGRAD) ? zz * p.mtiles + mt : mt;
+    float* part = smem + BM;          // [WAVES_M][BN][2], behind the row offsets
+    if constexpr (MODE != MODE_DGRAD) __syncthreads();       // every wave is done with the staged tiles
+    float mu[TN], rs[TN], ga[TN], be[TN], s1[TN], s2[TN];
+#pragma unroll
+    for (int ni = 0; ni < TN; ++ni) {
+      const int col = n0 + (wn * TN + ni) * 32 + r;
+      mu[ni] = rs[ni] = ga[ni] = be[ni] = s1[ni] = s2[ni] = 0.f;
+      if (cok[ni]) {
+        mu[ni] = p.bmean[col];
+        rs[ni] = p.binvstd[col];
+        if (p.bgamma) ga[ni] = p.bgamma[col];
+        if (p.bbeta) be[ni] = p.bbeta[col];
+      }
+    }
+    const float* xcol = p.bx + n0 + wn * TN * 32 + r;
+#pragma unroll
+    for (int mi = 0; mi < TM; ++mi) {
+      const int row_t = m0 + (wm * TM + mi) * 32 + 4 * h;
+      // all of the tile's x values first (the loads must not queue behind the stores further down), then the sums
+      float xv[16][TN];
+      unsigned ok_rows = 0;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int dr = (e & 3) + 8 * (e >> 2);
+        size_t off;
+        bool ok;
+        if constexpr (MODE == MODE_DGRAD) {
+          const unsigned o = row_off[(wm * TM + mi) * 32 + 4 * h + dr];
+          ok = o != NO_ROW;
+          off = o;
+        } else {
+          ok = row_t + dr < M;
+          off = (size_t)(row_t + dr) * p.Ncols;
+        }
+        ok_rows |= ok ? (1u << e) : 0u;
+#pragma unroll
+        for (int ni = 0; ni < TN; ++ni) xv[e][ni] = (ok && cok[ni]) ? xcol[off + ni * 32] : 0.f;
+      }
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        if (ok_rows & (1u << e)) {
+#pragma unroll
+          for (int ni = 0; ni < TN; ++ni) {
+            if (cok[ni]) {
+              float g = acc[mi][ni][e];
+              if (has_bias) g += bcol[ni];
+              if (p.bact != VG_ACT_NONE)
+                g *= vg_mask_grad(vg_bn_affine(xv[e][ni], mu[ni], rs[ni], p.bgamma, ga[ni], p.bbeta, be[ni]), p.bact, p.bslope);
+              s1[ni] += g;
+              s2[ni] = fmaf(g, (xv[e][ni] - mu[ni]) * rs[ni], s2[ni]);
+            }
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int ni = 0; ni < TN; ++ni) {
+      s1[ni] += __shfl_xor(s1[ni], 32, 64);
+      s2[ni] += __shfl_xor(s2[ni], 32, 64);
+      if (h == 0) {
+        part[(wm * BN + (wn * TN + ni) * 32 + r) * 2] = s1[ni];
+        part[(wm * BN + (wn * TN + ni) * 32 + r) * 2 + 1] = s2[ni];
+      }
+    }
+    __syncthreads();
+    if (tid < BN && n0 + tid < p.Ncols) {
+      double S1 = 0.0, S2 = 0.0;
+#pragma unroll
+      for (int w = 0; w < WAVES_M; ++w) {
+        S1 += (double)part[(w * BN + tid) * 2];
+        S2 += (double)part[(w * BN + tid) * 2 + 1];
+      }
+      double* st = p.stats + (size_t)tile * 2 * p.Ncols + n0 + tid;
+      st[0] = S1;
+      st[p.Ncols] = S2;
+    }
+    if (tid == 0 && nt == 0) p.stats[(size_t)p.stats_tiles * 2 * p.Ncols + tile] = (double)min(BM, M - m0);
+  }
 #pragma unroll
   for (int mi = 0; mi < TM; ++mi) {
     const int row_t = m0 + (wm * TM + mi) * 32 + 4 * h;      // first of the lane's 16 rows of this tile
@@ -837,6 +926,11 @@ __global__ void __launch_bounds__(NW * 64, NW == 8 ? 4 : 1) igemm_kernel(const I
   }
 }
 
+static inline void igemm_set_norm_bwd(IgemmParams& p, const VgNormBwdSrc& nb) {
+  p.bx = nb.x; p.bmean = nb.mean; p.binvstd = nb.invstd; p.bgamma = nb.gamma; p.bbeta = nb.beta;
+  p.bact = nb.act; p.bslope = nb.slope;
+}
+
 // Waves per block of the variant that serves (bm, bn, va, vb, prec).
 static inline int igemm_waves(int bm, int bn, int va, int vb, int prec) {
   const bool large = (bm == 128 && bn == 128) || (bm == 128 && bn == 64) || (bm == 64 && bn == 128);
@@ -858,9 +952,15 @@ static inline int igemm_launch(const IgemmParams& p, int bm, int bn, int va, int
   // two blocks bring four waves to every SIMD instead of two; measured +2..10 % on the DCGAN layers)
   if (igemm_waves(bm, bn, va, vb, prec) == 8 && p.stats) {
     if constexpr (MODE != MODE_WGRAD) {
-      if (bm == 128 && bn == 128) vg_launch_timed(igemm_kernel<MODE, 128, 128, 2, B_MC, 4, 4, PREC_F32, 8, true>, grid, dim3(512), 0, st, p);
-      else if (bm == 128) vg_launch_timed(igemm_kernel<MODE, 128, 64, 4, B_MC, 4, 4, PREC_F32, 8, true>, grid, dim3(512), 0, st, p);
-      else vg_launch_timed(igemm_kernel<MODE, 64, 128, 2, B_MC, 4, 4, PREC_F32, 8, true>, grid, dim3(512), 0, st, p);
+      if (p.bx) {
+        if (bm == 128 && bn == 128) vg_launch_timed(igemm_kernel<MODE, 128, 128, 2, B_MC, 4, 4, PREC_F32, 8, 2>, grid, dim3(512), 0, st, p);
+        else if (bm == 128) vg_launch_timed(igemm_kernel<MODE, 128, 64, 4, B_MC, 4, 4, PREC_F32, 8, 2>, grid, dim3(512), 0, st, p);
+        else vg_launch_timed(igemm_kernel<MODE, 64, 128, 2, B_MC, 4, 4, PREC_F32, 8, 2>, grid, dim3(512), 0, st, p);
+      } else {
+        if (bm == 128 && bn == 128) vg_launch_timed(igemm_kernel<MODE, 128, 128, 2, B_MC, 4, 4, PREC_F32, 8, 1>, grid, dim3(512), 0, st, p);
+        else if (bm == 128) vg_launch_timed(igemm_kernel<MODE, 128, 64, 4, B_MC, 4, 4, PREC_F32, 8, 1>, grid, dim3(512), 0, st, p);
+        else vg_launch_timed(igemm_kernel<MODE, 64, 128, 2, B_MC, 4, 4, PREC_F32, 8, 1>, grid, dim3(512), 0, st, p);
+      }
       return 0;
     }
   }

@@ -182,17 +182,6 @@ __device__ __forceinline__ float act_grad(float ref, int act, float slope) {
 }
 
 
-// The norm's pre-activation value, v = (x - mean) * (invstd * gamma) + beta, in ONE fixed sequence of operations (a
-// subtraction, a product for the scale, a fused multiply-add). The forward pass and the backward kernels that rebuild
-// the fused activation's slope mask from x instead of reading the activation's output both call this, so the mask is
-// the sign the forward pass saw, bit for bit.
-__device__ __forceinline__ float bn_affine(float a, float mu, float r, const float* gamma, float ga, const float* beta,
-                                           float be) {
-  const float sc = gamma ? r * ga : r;
-  const float d = a - mu;
-  return beta ? __builtin_fmaf(d, sc, be) : d * sc;
-}
-
 // ---- functors -------------------------------------------------------------------------------------
 struct SumF {  // colsum
   const float* x;
@@ -243,7 +232,7 @@ struct BnBwdF {  // sum g, sum g*xhat with g = gy * act'(.) when an activation i
       if (gamma) ldv<VEC>(gamma + c, ga);
       if (beta) ldv<VEC>(beta + c, be);
 #pragma unroll
-      for (int e = 0; e < VEC; ++e) g[e] *= act_grad(bn_affine(a[e], mu[e], r[e], gamma, ga[e], beta, be[e]), act, slope);
+      for (int e = 0; e < VEC; ++e) g[e] *= act_grad(vg_bn_affine(a[e], mu[e], r[e], gamma, ga[e], beta, be[e]), act, slope);
     }
 #pragma unroll
     for (int e = 0; e < VEC; ++e) {
@@ -276,7 +265,7 @@ struct BnDbwdF {  // sum g, sum g*xhat, sum u, sum u*xhat, sum u*g   (g as in Bn
       if (gamma) ldv<VEC>(gamma + c, ga);
       if (beta) ldv<VEC>(beta + c, be);
 #pragma unroll
-      for (int e = 0; e < VEC; ++e) g[e] *= act_grad(bn_affine(a[e], mu[e], r[e], gamma, ga[e], beta, be[e]), act, slope);
+      for (int e = 0; e < VEC; ++e) g[e] *= act_grad(vg_bn_affine(a[e], mu[e], r[e], gamma, ga[e], beta, be[e]), act, slope);
     }
 #pragma unroll
     for (int e = 0; e < VEC; ++e) {
@@ -386,6 +375,60 @@ __global__ void __launch_bounds__(1024) bn_tiles_final_kernel(const double* __re
   }
 }
 
+// The two column sums of a BatchNorm's backward pass from the per-tile sums a convolution's epilogue left (igemm.h,
+// STATS = 2): [tiles][2][C] doubles, then [tiles] row counts (0 = the tile wrote nothing). Same block shape and fixed
+// tree as above; the result leaves as f32 [2][C] (sum g m, sum g m xhat), what vg_bn_bwd_reduce leaves.
+__global__ void __launch_bounds__(1024) bn_bwd_tiles_final_kernel(const double* __restrict__ part, int tiles, int C,
+                                                                  float* __restrict__ sums) {
+  constexpr int COLS = 4, LANES = 1024 / COLS;
+  __shared__ double red[2][1024];
+  const int cl = threadIdx.x % COLS, q = threadIdx.x / COLS;
+  const int c = blockIdx.x * COLS + cl;
+  const double* counts = part + (size_t)tiles * 2 * C;
+  double a = 0.0, b = 0.0;
+  if (c < C) {
+    int t = q;
+    for (; t + 3 * LANES < tiles; t += 4 * LANES) {
+      double n[4], s1[4], s2[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const size_t base = ((size_t)(t + LANES * u) * 2) * C + c;
+        n[u] = counts[t + LANES * u];
+        s1[u] = part[base];
+        s2[u] = part[base + C];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (n[u] > 0.0) {
+          a += s1[u];
+          b += s2[u];
+        }
+      }
+    }
+    for (; t < tiles; t += LANES) {
+      if (counts[t] > 0.0) {
+        const size_t base = ((size_t)t * 2) * C + c;
+        a += part[base];
+        b += part[base + C];
+      }
+    }
+  }
+  red[0][threadIdx.x] = a;
+  red[1][threadIdx.x] = b;
+  __syncthreads();
+  for (int half = LANES / 2; half > 0; half >>= 1) {
+    if (q < half) {
+      red[0][threadIdx.x] += red[0][threadIdx.x + half * COLS];
+      red[1][threadIdx.x] += red[1][threadIdx.x + half * COLS];
+    }
+    __syncthreads();
+  }
+  if (q == 0 && c < C) {
+    sums[c] = (float)red[0][cl];
+    sums[C + c] = (float)red[1][cl];
+  }
+}
+
 __global__ void __launch_bounds__(256) invstd_kernel(const float* var, float* invstd, int C, float eps) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c < C) invstd[c] = 1.0f / sqrtf(var[c] + eps);
@@ -407,7 +450,7 @@ __global__ void __launch_bounds__(256) bn_apply_kernel(const float* __restrict__
     if (gamma) ldv<VEC>(gamma + c, ga);
     if (beta) ldv<VEC>(beta + c, be);
 #pragma unroll
-    for (int e = 0; e < VEC; ++e) o[e] = act_apply(bn_affine(a[e], mu[e], r[e], gamma, ga[e], beta, be[e]), act, slope);
+    for (int e = 0; e < VEC; ++e) o[e] = act_apply(vg_bn_affine(a[e], mu[e], r[e], gamma, ga[e], beta, be[e]), act, slope);
     stv<VEC>(y + i * VEC, o);
   }
 }
@@ -438,7 +481,7 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const float* __restri
       float be[VEC];
       if (beta) ldv<VEC>(beta + c, be);
 #pragma unroll
-      for (int e = 0; e < VEC; ++e) g[e] *= act_grad(bn_affine(a[e], mu[e], r[e], gamma, ga[e], beta, be[e]), act, slope);
+      for (int e = 0; e < VEC; ++e) g[e] *= act_grad(vg_bn_affine(a[e], mu[e], r[e], gamma, ga[e], beta, be[e]), act, slope);
     }
     ldv<VEC>(sums + c, sg);
     ldv<VEC>(sums + C + c, sgx);
@@ -501,7 +544,7 @@ __global__ void __launch_bounds__(256) bn_dbwd_apply_kernel(
       float be[VEC];
       if (beta) ldv<VEC>(beta + c, be);
 #pragma unroll
-      for (int e = 0; e < VEC; ++e) mk[e] = act_grad(bn_affine(a[e], mu[e], r[e], gamma, ga[e], beta, be[e]), act, slope);
+      for (int e = 0; e < VEC; ++e) mk[e] = act_grad(vg_bn_affine(a[e], mu[e], r[e], gamma, ga[e], beta, be[e]), act, slope);
     }
 #pragma unroll
     for (int e = 0; e < VEC; ++e) g[e] *= mk[e];
@@ -660,6 +703,17 @@ extern "C" int vg_bn_stats_from_conv(int mode, const vg_conv_geom* g, const void
   hipLaunchKernelGGL(bn_tiles_final_kernel, dim3((C + 3) / 4), dim3(1024), 0, (hipStream_t)stream, (const double*)stats, tiles,
                      C, (double)rows, fin);
   VG_CHECK_LAUNCH("vg_bn_stats_from_conv");
+  return VG_OK;
+}
+
+extern "C" int vg_bn_bwd_sums_from_conv(int mode, const vg_conv_geom* g, const void* tile_sums, float* sums, void* stream) {
+  VG_REQUIRE(g && tile_sums && sums && (mode == 0 || mode == 1), "vg_bn_bwd_sums_from_conv: bad arguments");
+  int tiles, C;
+  long long rows;
+  vg_bnstats_layout(mode, g, &tiles, &rows, &C);
+  hipLaunchKernelGGL(bn_bwd_tiles_final_kernel, dim3((C + 3) / 4), dim3(1024), 0, (hipStream_t)stream,
+                     (const double*)tile_sums, tiles, C, sums);
+  VG_CHECK_LAUNCH("vg_bn_bwd_sums_from_conv");
   return VG_OK;
 }
 

@@ -36,6 +36,32 @@ static inline int vg_stream_grid(size_t work_items, int block) {
   return (int)blocks;
 }
 
+// The BatchNorm pre-activation value, v = (x - mean) * (invstd * gamma) + beta, in ONE fixed sequence of operations (a
+// subtraction, a product for the scale, a fused multiply-add). The forward pass and every kernel that rebuilds the
+// fused activation's slope mask from x instead of reading the activation's output call this, so the mask is the sign
+// the forward pass saw, bit for bit.
+__device__ __forceinline__ float vg_bn_affine(float a, float mu, float r, const float* gamma, float ga, const float* beta,
+                                              float be) {
+  const float sc = gamma ? r * ga : r;
+  const float d = a - mu;
+  return beta ? __builtin_fmaf(d, sc, be) : d * sc;
+}
+
+// A BatchNorm (+ fused ReLU / LeakyReLU) whose output gradient a convolution is about to produce: its input x (laid out
+// like the convolution's output), batch statistics, affine parameters (null = none) and activation.
+struct VgNormBwdSrc {
+  const float *x, *mean, *invstd, *gamma, *beta;
+  int act;
+  float slope;
+};
+
+// slope of ReLU / LeakyReLU at a value of that sign (other codes: 1)
+__device__ __forceinline__ float vg_mask_grad(float ref, int act, float slope) {
+  if (act == VG_ACT_RELU) return ref > 0.f ? 1.f : 0.f;
+  if (act == VG_ACT_LRELU) return ref > 0.f ? 1.f : slope;
+  return 1.f;
+}
+
 __device__ __forceinline__ float vg_wave_sum(float v) {
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);

@@ -87,6 +87,9 @@ SIGNATURES = {
     "vg_conv2d_bnstats_workspace_bytes": (c_size_t, [c_int, _P]),
     "vg_conv2d_fwd_bnstats": (c_int, [_P, _P, _P, _P, _P, _P, c_size_t, _P, _P]),
     "vg_conv2d_dgrad_bnstats": (c_int, [_P, _P, _P, _P, _P, _P, c_size_t, _P, _P]),
+    "vg_conv2d_fwd_bnbwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_float, _P, c_size_t, _P, _P]),
+    "vg_conv2d_dgrad_bnbwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_float, _P, c_size_t, _P, _P]),
+    "vg_bn_bwd_sums_from_conv": (c_int, [c_int, _P, _P, _P, _P]),
     "vg_bn_stats_from_conv": (c_int, [c_int, _P, _P, c_float, c_float, _P, _P, _P, _P, _P, _P]),
     "vg_bn_apply": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_float, _P]),
     "vg_bn_bwd_reduce": (c_int, [_P, _P, _P, _P, c_int, c_int, _P, _P, c_size_t, _P, c_int, c_float, _P, _P, _P]),

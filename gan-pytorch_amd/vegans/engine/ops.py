@@ -18,6 +18,7 @@ Memory layout: 4-d activations are NCHW-shaped tensors with channels_last stride
 are kept channels_last as well ([Co][kh][kw][Ci] in memory).  Tensors that arrive in another layout are
 re-laid-out by the layout kernels, never by torch.
 """
+import collections
 import ctypes
 import os
 from ctypes import c_float, c_int, c_size_t
@@ -347,19 +348,92 @@ class _NormStats:
 norm_stats = _NormStats()
 
 
-def _conv_with_stats(mode, g, args, out):
-    """Run the convolution through the entry point that also leaves column statistics; True when it did."""
+NormSource = collections.namedtuple("NormSource", "x mean invstd gamma beta act slope")
+
+
+class _NormBackwardSums:
+    """Hand-over, in the backward pass, of the two column sums a training-mode BatchNorm needs (sum g m, sum g m xhat)
+    from the convolution kernel that PRODUCES the gradient g arriving at the norm's output. In the forward pass the norm
+    notes its output and what describes it (`produced`); the convolution that takes exactly that tensor as its input
+    keeps the description (`source_of`); when that convolution's backward computes its input gradient it asks the
+    contraction kernel for the sums (`request` ... `take_request`), which leaves them beside the gradient (`offer`); the
+    norm's backward operator takes them if, and only if, the gradient it is handed IS that tensor, unmodified
+    (`claim`: same memory, same version counter, same norm). A gradient that autograd summed from several consumers
+    is another tensor (or a later version) and is reduced the ordinary way."""
+
+    def __init__(self):
+        self.last_output = None     # (output tensor of the latest training-mode norm, its NormSource)
+        self.wanted = None
+        self.ready = None           # (gradient tensor, its version, mode, geometry, per-tile sums, NormSource)
+
+    def produced(self, y, src):
+        self.last_output = (y, src)
+
+    def source_of(self, t):
+        last = self.last_output
+        if last is None or last[0].data_ptr() != t.data_ptr() or last[0].shape != t.shape:
+            return None
+        return last[1]
+
+    def request(self, src):
+        self.wanted = src
+
+    def cancel(self):
+        self.wanted = None
+
+    def take_request(self):
+        src, self.wanted = self.wanted, None
+        return src if _precision == 0 else None
+
+    def offer(self, gx, mode, g, sums, src):
+        self.ready = (gx, gx._version, mode, g, sums, src)
+
+    def claim(self, gy, mean):
+        """The per-tile sums left beside gradient `gy` for the norm whose batch mean is the tensor `mean` (allocated by
+        that norm's forward call, so it names the call), or None."""
+        ready, self.ready = self.ready, None
+        if ready is None:
+            return None
+        t, version, mode, g, sums, src = ready
+        if gy.data_ptr() != t.data_ptr() or gy._version != version or gy.shape != t.shape:
+            return None
+        if src.mean.data_ptr() != mean.data_ptr():
+            return None
+        return mode, g, sums
+
+    def clear(self):
+        self.last_output = self.wanted = self.ready = None
+
+
+norm_bwd = _NormBackwardSums()
+
+
+def _conv_with_stats(mode, g, args, out, src=None):
+    """Run the convolution through an entry point whose epilogue also leaves per-tile column sums: the batch statistics
+    of the output (src None), or the backward sums of the norm `src` whose output gradient `out` is. True when the
+    convolution ran."""
     lib = _hip.load()
     nbytes = lib.vg_conv2d_bnstats_workspace_bytes(mode, ctypes.byref(g.c))
     if not nbytes:
         return False
+    if src is not None and (_rows_cols(src.x) != _rows_cols(out) or not src.x.is_contiguous(
+            memory_format=CL if src.x.dim() == 4 else torch.contiguous_format)):
+        return False
     stats = torch.empty(nbytes, dtype=torch.uint8, device=out.device)
     written = ctypes.c_int(0)
-    name = "vg_conv2d_fwd_bnstats" if mode == 0 else "vg_conv2d_dgrad_bnstats"
-    _launch_conv(mode, g, lambda: call(name, ctypes.byref(g.c), *args, _ptr(out), ctypes.c_void_p(stats.data_ptr()),
-                                       c_size_t(nbytes), ctypes.byref(written), _stream()))
-    if written.value:
-        norm_stats.offer(out, mode, g, stats)
+    tail = (ctypes.c_void_p(stats.data_ptr()), c_size_t(nbytes), ctypes.byref(written), _stream())
+    if src is None:
+        name = "vg_conv2d_fwd_bnstats" if mode == 0 else "vg_conv2d_dgrad_bnstats"
+        _launch_conv(mode, g, lambda: call(name, ctypes.byref(g.c), *args, _ptr(out), *tail))
+        if written.value:
+            norm_stats.offer(out, mode, g, stats)
+    else:
+        name = "vg_conv2d_fwd_bnbwd" if mode == 0 else "vg_conv2d_dgrad_bnbwd"
+        _launch_conv(mode, g, lambda: call(name, ctypes.byref(g.c), *args, _ptr(out), _ptr(src.x), _ptr(src.mean),
+                                           _ptr(src.invstd), _ptr(src.gamma), _ptr(src.beta), src.act,
+                                           c_float(src.slope), *tail))
+        if written.value:
+            norm_bwd.offer(out, mode, g, stats, src)
     return True
 
 
@@ -369,7 +443,12 @@ def raw_conv_fwd(g, x, w, bias):
     if w.numel() != g.w_numel():
         raise _hip.HipError("weight has %d elements, geometry expects %d" % (w.numel(), g.w_numel()))
     y = _new_act(g.N, g.Co, g.Ho, g.Wo, x, g.flat)
-    if norm_stats.take_request() and _conv_with_stats(0, g, (_ptr(x), _ptr(w), _ptr(bias)), y):
+    src = norm_bwd.take_request()
+    if norm_stats.take_request():
+        src = None
+    elif src is None:
+        src = False
+    if src is not False and _conv_with_stats(0, g, (_ptr(x), _ptr(w), _ptr(bias)), y, src):
         return y
     nbytes, wsp = _conv_workspace(0, g, x.device)
     xp, wp = plane_cache.pointer(0, g, x), plane_cache.pointer(0, g, w)
@@ -384,7 +463,12 @@ def raw_conv_dgrad(g, gy, w, bias):
     if w.numel() != g.w_numel():
         raise _hip.HipError("weight has %d elements, geometry expects %d" % (w.numel(), g.w_numel()))
     gx = _new_act(g.N, g.Ci, g.H, g.W, gy, g.flat)
-    if norm_stats.take_request() and _conv_with_stats(1, g, (_ptr(gy), _ptr(w), _ptr(bias)), gx):
+    src = norm_bwd.take_request()
+    if norm_stats.take_request():
+        src = None
+    elif src is None:
+        src = False
+    if src is not False and _conv_with_stats(1, g, (_ptr(gy), _ptr(w), _ptr(bias)), gx, src):
         return gx
     nbytes, wsp = _conv_workspace(1, g, gy.device)
     gp, wp = plane_cache.pointer(1, g, gy), plane_cache.pointer(1, g, w)
@@ -455,6 +539,7 @@ class ConvFwdFn(Function):
         ctx.g = g
         ctx.label = _label(label)
         ctx.save_for_backward(x, w, bias)
+        ctx.norm_src = norm_bwd.source_of(x)     # x is the output of a training-mode norm: see _NormBackwardSums
         return raw_conv_fwd(g, x, w, bias)
 
     @staticmethod
@@ -462,7 +547,11 @@ class ConvFwdFn(Function):
         x, w, bias = ctx.saved_tensors
         g, lab = ctx.g, ctx.label
         params = not inputs_only.active
-        gx = ConvDgradFn.apply(gy, w, None, g, lab + (0,)) if _wants_input_grad(ctx, x) else None
+        gx = None
+        if _wants_input_grad(ctx, x):
+            norm_bwd.request(ctx.norm_src)
+            gx = ConvDgradFn.apply(gy, w, None, g, lab + (0,))
+            norm_bwd.cancel()
         gw = ConvWgradFn.apply(gy, x, g, tuple(w.shape), lab + (1,)) if (params and ctx.needs_input_grad[1]) else None
         gb = ColSumFn.apply(gy) if (params and bias is not None and ctx.needs_input_grad[2]) else None
         return gx, grads.route(w, lab, gw), grads.route(bias, lab, gb), None, None
@@ -507,6 +596,7 @@ class ConvDgradFn(Function):
         ctx.g = g
         ctx.label = _label(label)
         ctx.save_for_backward(gy, w, bias)
+        ctx.norm_src = norm_bwd.source_of(gy)    # as in ConvFwdFn: the transposed convolution behind a norm
         return raw_conv_dgrad(g, gy, w, bias)
 
     @staticmethod
@@ -514,7 +604,11 @@ class ConvDgradFn(Function):
         gy, w, bias = ctx.saved_tensors
         g, lab = ctx.g, ctx.label
         params = not inputs_only.active
-        d_gy = ConvFwdFn.apply(ggx, w, None, g, lab + (0,)) if _wants_input_grad(ctx, gy) else None
+        d_gy = None
+        if _wants_input_grad(ctx, gy):
+            norm_bwd.request(ctx.norm_src)
+            d_gy = ConvFwdFn.apply(ggx, w, None, g, lab + (0,))
+            norm_bwd.cancel()
         d_w = ConvWgradFn.apply(gy, ggx, g, tuple(w.shape), lab + (1,)) if (params and ctx.needs_input_grad[1]) else None
         d_b = ColSumFn.apply(ggx) if (params and bias is not None and ctx.needs_input_grad[2]) else None
         return d_gy, grads.route(w, lab, d_w), grads.route(bias, lab, d_b), None, None
@@ -672,6 +766,7 @@ class BatchNormTrainFn(Function):
              act, c_float(slope), _stream())
         ctx.act, ctx.slope = act, slope
         ctx.label = grads.ticket()
+        norm_bwd.produced(y, NormSource(x, mean, invstd, gamma, beta, act, slope))
         tap = x_in.view_as(x_in)
         ctx.save_for_backward(tap, gamma, beta, mean, invstd)
         ctx.set_materialize_grads(False)
@@ -705,13 +800,18 @@ class BatchNormBwdFn(Function):
         ctx.save_for_backward(gy, x, gamma, mean, invstd, mask_beta)
         ctx.act, ctx.slope = act, slope
         ctx.label = _label(label)
+        left = norm_bwd.claim(gy, mean)
         gy, x = to_nhwc(gy), to_nhwc(x)
         m, c = _rows_cols(x)
         mask = _act_args(act, slope)
         sums = torch.empty((2, c), dtype=torch.float32, device=x.device)
-        ws, nbytes = _bn_ws(m, c, x.device)
-        call("vg_bn_bwd_reduce", _ptr(gy), _ptr(x), _ptr(mean), _ptr(invstd), m, c, _ptr(sums),
-             ctypes.c_void_p(ws.data_ptr()), c_size_t(nbytes), *mask, _ptr(gamma), _ptr(mask_beta), _stream())
+        if left is not None:          # the kernel that produced gy left the two sums per row tile: add the tiles
+            call("vg_bn_bwd_sums_from_conv", left[0], ctypes.byref(left[1].c), ctypes.c_void_p(left[2].data_ptr()),
+                 _ptr(sums), _stream())
+        else:
+            ws, nbytes = _bn_ws(m, c, x.device)
+            call("vg_bn_bwd_reduce", _ptr(gy), _ptr(x), _ptr(mean), _ptr(invstd), m, c, _ptr(sums),
+                 ctypes.c_void_p(ws.data_ptr()), c_size_t(nbytes), *mask, _ptr(gamma), _ptr(mask_beta), _stream())
         gx = torch.empty_like(x)
         call("vg_bn_bwd_apply", _ptr(gy), _ptr(x), _ptr(mean), _ptr(invstd), _ptr(gamma), _ptr(sums), _ptr(gx), m, c,
              *mask, _ptr(mask_beta), _stream())

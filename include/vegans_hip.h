@@ -227,6 +227,26 @@ int vg_bn_bwd_reduce(const float* gy, const float* x, const float* mean, const f
 int vg_bn_bwd_apply(const float* gy, const float* x, const float* mean, const float* invstd,
                     const float* gamma, const float* sums, float* gx, int M, int C, const float* act_out, int act,
                     float slope, const float* beta, void* stream);
+/* The two sums of vg_bn_bwd_reduce without a pass over (gy, x): when the gradient that arrives at a BatchNorm's output
+ * is itself the output of a convolution kernel (the input gradient of the Conv2d behind the norm: vg_conv2d_dgrad_bnbwd;
+ * the input gradient of a ConvTranspose2d behind it, which is a forward convolution: vg_conv2d_fwd_bnbwd), that kernel's
+ * epilogue reads the norm's input bn_x at the positions it writes ([rows][channels], laid out like the convolution's
+ * output), rebuilds the slope mask of the activation fused behind the norm (act, slope; bn_gamma / bn_beta nullable as
+ * in vg_bn_apply) and leaves per row tile and channel sum (g m) and sum (g m xhat) in `sums`
+ * (vg_conv2d_bnstats_workspace_bytes(mode, g) bytes, 16-byte aligned); vg_bn_bwd_sums_from_conv adds the tiles (double,
+ * fixed order) into the f32 [2][C] that vg_bn_bwd_apply takes. The convolution's own result is exactly that of
+ * vg_conv2d_fwd / vg_conv2d_dgrad; *sums_written is 0 when the geometry ran on a kernel without this epilogue (the
+ * caller then uses vg_bn_bwd_reduce). Reference: the backward pass autograd runs through nn.BatchNorm2d + ReLU /
+ * LeakyReLU in front of nn.Conv2d / nn.ConvTranspose2d (examples/example_input_formats.py:52-77). */
+int vg_conv2d_fwd_bnbwd(const vg_conv_geom* g, const float* x, const float* w, const float* bias, float* y,
+                        const float* bn_x, const float* bn_mean, const float* bn_invstd, const float* bn_gamma,
+                        const float* bn_beta, int act, float slope, void* sums, size_t sums_bytes, int* sums_written,
+                        void* stream);
+int vg_conv2d_dgrad_bnbwd(const vg_conv_geom* g, const float* gy, const float* w, const float* bias, float* gx,
+                          const float* bn_x, const float* bn_mean, const float* bn_invstd, const float* bn_gamma,
+                          const float* bn_beta, int act, float slope, void* sums, size_t sums_bytes, int* sums_written,
+                          void* stream);
+int vg_bn_bwd_sums_from_conv(int mode, const vg_conv_geom* g, const void* tile_sums, float* sums, void* stream);
 /* eval-mode backward: gx = gy * gamma * invstd */
 int vg_bn_bwd_eval(const float* gy, const float* invstd, const float* gamma, float* gx, int M, int C,
                    void* stream);

@@ -858,3 +858,102 @@ def test_batch_statistics_from_the_convolution_epilogue(gpu, kind, shape, served
     _close(outs[True][0], want, 2e-5, "conv + batch norm output vs torch")
     _close(outs[True][1], ref[1].running_mean, 2e-5, "running mean vs torch")
     _close(outs[True][2], ref[1].running_var, 2e-5, "running var vs torch")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind,shape,act,served_by_epilogue", [
+    # (N, H, W of the norm's activation, its channels C, the next layer's channels, k, s, p)
+    ("conv", (64, 32, 32, 64, 128, 4, 2, 1), "lrelu", True),      # input gradient of a strided convolution: 4 classes
+    ("conv", (5, 17, 13, 96, 32, 3, 1, 1), "relu", True),         # ragged last row tile, 96 of 128 columns
+    ("conv", (16, 16, 16, 256, 64, 4, 2, 1), "lrelu", True),      # two column tiles
+    ("conv", (24, 15, 14, 128, 64, 4, 2, 1), "none", True),       # no activation between norm and convolution
+    ("conv", (4, 9, 9, 16, 8, 3, 1, 1), "relu", False),           # too small for the eight-wave tiles: separate pass
+    ("convT", (64, 16, 16, 128, 64, 4, 2, 1), "relu", True),      # input gradient of a transposed convolution
+    ("convT", (7, 11, 9, 128, 32, 4, 2, 1), "relu", True),        # ragged
+    ("convT", (32, 8, 8, 256, 128, 3, 1, 1), "lrelu", True),      # stride 1
+])
+def test_norm_backward_sums_from_the_convolution_epilogue(gpu, kind, shape, act, served_by_epilogue):
+    """BatchNorm (+ activation) in front of a (transposed) convolution: in the backward pass the kernel that produces
+    the gradient arriving at the norm also leaves the norm's two column sums. Gradients of the norm's input, gamma and
+    beta must agree with the separate reduction pass to rounding (5e-6 of scale), and both with torch (float64)."""
+    import copy
+    from torch import nn
+    from vegans.engine import modules, ops
+    N, H, W, C, Co, k, s, p = shape
+    torch.manual_seed(11)
+    tail = nn.Conv2d(C, Co, k, s, p) if kind == "conv" else nn.ConvTranspose2d(C, Co, k, s, p)
+    layers = [nn.BatchNorm2d(C)] + ({"relu": [nn.ReLU()], "lrelu": [nn.LeakyReLU(0.2)], "none": []}[act]) + [tail]
+    ref = nn.Sequential(*layers)
+    with torch.no_grad():
+        ref[0].weight.uniform_(0.5, 1.5)
+        ref[0].bias.uniform_(-0.5, 0.5)
+    x = torch.randn(N, C, H, W) * 1.5 + 0.3
+    probe = torch.randn_like(ref(x))
+
+    def run(net, xin, weight):
+        xin = xin.clone().requires_grad_(True)
+        (net(xin) * weight).sum().backward()
+        return [t.detach().double().cpu() for t in (xin.grad, net[0].weight.grad, net[0].bias.grad)]
+
+    want = run(copy.deepcopy(ref).double(), x.double(), probe.double())
+    outs = {}
+    for fused in (True, False):
+        net = copy.deepcopy(ref).to("cuda")
+        modules.bind(net)
+        modules.prepare_parameters(net)
+        net.train()
+        seen = []
+        orig_claim, orig_source = ops.norm_bwd.claim, ops.norm_bwd.source_of
+        ops.norm_bwd.claim = lambda *a: seen.append(orig_claim(*a)) or seen[-1]
+        if not fused:
+            ops.norm_bwd.source_of = lambda t: None
+        try:
+            outs[fused] = run(net, x.to("cuda"), probe.to("cuda"))
+        finally:
+            ops.norm_bwd.claim, ops.norm_bwd.source_of = orig_claim, orig_source
+        assert len(seen) == 1
+        if fused:
+            assert (seen[0] is not None) == served_by_epilogue, shape
+        else:
+            assert seen[0] is None
+    for name, a, b, w in zip(("gx", "ggamma", "gbeta"), outs[True], outs[False], want):
+        _close(a, b, 5e-6, "%s: sums from the epilogue vs separate pass" % name)
+        _close(a, w, 3e-5, "%s vs torch float64" % name)
+
+
+@pytest.mark.gpu
+def test_norm_backward_sums_are_not_taken_when_the_gradient_was_summed(gpu):
+    """The norm's output feeds TWO consumers: the gradient at the norm is a sum autograd forms, not the tensor the
+    convolution kernel wrote, so the per-tile sums that kernel left must be ignored."""
+    from torch import nn
+    from vegans.engine import modules, ops
+    torch.manual_seed(3)
+    norm, conv = nn.BatchNorm2d(64), nn.Conv2d(64, 64, 3, 1, 1)
+    block = nn.Sequential(norm, nn.ReLU())
+    x = torch.randn(16, 64, 16, 16)
+
+    probe = torch.randn(16, 64, 16, 16)
+
+    def run(block, conv, xin):
+        xin = xin.clone().requires_grad_(True)
+        h = block(xin)
+        ((conv(h) * probe.to(xin)).sum() + (h * h).sum()).backward()
+        return [t.detach().double().cpu() for t in (xin.grad, block[0].weight.grad, block[0].bias.grad)]
+
+    import copy
+    want = run(copy.deepcopy(block).double(), copy.deepcopy(conv).double(), x.double())
+    gb, gc = copy.deepcopy(block).to("cuda"), nn.Sequential(copy.deepcopy(conv)).to("cuda")
+    for net in (gb, gc):
+        modules.bind(net)
+        modules.prepare_parameters(net)
+        net.train()
+    seen = []
+    orig = ops.norm_bwd.claim
+    ops.norm_bwd.claim = lambda *a: seen.append(orig(*a)) or seen[-1]
+    try:
+        got = run(gb, gc, x.to("cuda"))
+    finally:
+        ops.norm_bwd.claim = orig
+    assert seen == [None]
+    for name, a, w in zip(("gx", "ggamma", "gbeta"), got, want):
+        _close(a, w, 3e-5, "%s vs torch float64" % name)
