@@ -45,6 +45,14 @@ extern "C" int vg_conv2d_dgrad_bnbwd(const vg_conv_geom* g, const float* gy, con
   return conv_dgrad_impl(g, gy, w, bias, gx, VG_PREC_F32, nullptr, 0, nullptr, nullptr, (double*)sums, sums_written, &nb, stream);
 }
 
+extern "C" int vg_conv2d_dgrad_actmask(const vg_conv_geom* g, const float* gy, const float* w, float* gx,
+                                       const float* act_out, int act, float slope, int* masked, void* stream) {
+  VG_REQUIRE(act_out && masked, "vg_conv2d_dgrad_actmask: null activation output or flag pointer");
+  VG_REQUIRE(act == VG_ACT_RELU || act == VG_ACT_LRELU, "vg_conv2d_dgrad_actmask: only ReLU / LeakyReLU have a slope mask");
+  const VgNormBwdSrc nb{act_out, nullptr, nullptr, nullptr, nullptr, act, slope};
+  return conv_dgrad_impl(g, gy, w, nullptr, gx, VG_PREC_F32, nullptr, 0, nullptr, nullptr, nullptr, masked, &nb, stream);
+}
+
 static int conv_dgrad_impl(const vg_conv_geom* g, const float* gy, const float* w, const float* bias, float* gx,
                            int precision, void* workspace, size_t workspace_bytes, const void* gy_planes,
                            const void* w_planes, double* stats, int* stats_written, const VgNormBwdSrc* nb, void* stream) {
@@ -105,6 +113,14 @@ static int conv_dgrad_impl(const vg_conv_geom* g, const float* gy, const float* 
       return VG_OK;
     }
     p.stats = nullptr;
+    p.bx = nullptr;
+  } else if (nb) {   // no sums asked for: the slope mask alone, where the plan has such a kernel
+    igemm_set_norm_bwd(p, *nb);
+    if (igemm_launch<MODE_DGRAD, true>(p, bm, bn, va, vb, grid, (hipStream_t)stream, precision) == 0) {
+      VG_CHECK_LAUNCH("vg_conv2d_dgrad(slope mask)");
+      *stats_written = 1;
+      return VG_OK;
+    }
     p.bx = nullptr;
   }
   if (igemm_launch<MODE_DGRAD, true>(p, bm, bn, va, vb, grid, (hipStream_t)stream, precision) != 0)

@@ -83,6 +83,8 @@ static inline int igemm_set_operands(IgemmParams& p, long long a_elems, long lon
 // STATS = 1: the epilogue also leaves, per row tile and column, the statistics a BatchNorm behind the convolution needs
 // (a shift value, the sum of (y - shift) and the sum of (y - shift)^2 over the tile's valid rows, and the tile's row
 // count), so the norm does not have to read the output again to get its batch mean and variance.
+// STATS = 3 (input-gradient mode): the output is the gradient arriving at the output of a ReLU / LeakyReLU; it is
+// multiplied by that activation's slope mask before it is stored (no sums).
 // STATS = 2: the output is the gradient g arriving at the output of a BatchNorm (+ ReLU / LeakyReLU) whose input x is
 // at hand: the epilogue leaves, per row tile and column, sum (g m) and sum (g m xhat) (m the activation's slope mask,
 // xhat the normalised input), the two sums that norm's backward pass needs before it can form its input gradient.
@@ -155,7 +157,7 @@ __global__ void __launch_bounds__(NW * 64, NW == 8 ? 4 : 1) igemm_kernel(const I
     Ktot = nth * ntw * p.Co;
     kend = Ktot;
     if (m0 >= M) {        // block-uniform
-      if constexpr (STATS != 0) {
+      if constexpr (STATS == 1 || STATS == 2) {      // a tile of this class's surplus: it has no rows
         constexpr int NQ = STATS == 1 ? 3 : 2;
         if (nt == 0 && tid == 0) p.stats[(size_t)p.stats_tiles * NQ * p.Ncols + (zz * p.mtiles + mt)] = 0.0;
       }
@@ -896,6 +898,30 @@ __global__ void __launch_bounds__(NW * 64, NW == 8 ? 4 : 1) igemm_kernel(const I
     }
     if (tid == 0 && nt == 0) p.stats[(size_t)p.stats_tiles * 2 * p.Ncols + tile] = (double)min(BM, M - m0);
   }
+  if constexpr (STATS == 3 && MODE == MODE_DGRAD) {
+    // the output is a gradient arriving at the output of a ReLU / LeakyReLU whose result bx holds (laid out like the
+    // output): multiply by the activation's slope at each position, so what is stored is the gradient in front of it
+    const float* rcol = p.bx + n0 + wn * TN * 32 + r;
+#pragma unroll
+    for (int mi = 0; mi < TM; ++mi) {
+      float rv[16][TN];
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const unsigned o = row_off[(wm * TM + mi) * 32 + 4 * h + (e & 3) + 8 * (e >> 2)];
+#pragma unroll
+        for (int ni = 0; ni < TN; ++ni) rv[e][ni] = (o != NO_ROW && cok[ni]) ? rcol[(size_t)o + ni * 32] : 1.f;
+      }
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+#pragma unroll
+        for (int ni = 0; ni < TN; ++ni) {
+          if (has_bias) acc[mi][ni][e] += bcol[ni];
+          acc[mi][ni][e] *= vg_mask_grad(rv[e][ni], p.bact, p.bslope);
+        }
+      }
+    }
+    has_bias = false;
+  }
 #pragma unroll
   for (int mi = 0; mi < TM; ++mi) {
     const int row_t = m0 + (wm * TM + mi) * 32 + 4 * h;      // first of the lane's 16 rows of this tile
@@ -950,6 +976,16 @@ static inline int igemm_launch(const IgemmParams& p, int bm, int bn, int va, int
   }
   // f32, 16-byte-vector operands: eight waves per block on the three large tiles (half the accumulators per wave, so
   // two blocks bring four waves to every SIMD instead of two; measured +2..10 % on the DCGAN layers)
+  if (p.bx && !p.stats) {      // slope mask of an activation applied to the stored gradient
+    if constexpr (MODE == MODE_DGRAD) {
+      if (igemm_waves(bm, bn, va, vb, prec) != 8) return -3;
+      if (bm == 128 && bn == 128) vg_launch_timed(igemm_kernel<MODE, 128, 128, 2, B_MC, 4, 4, PREC_F32, 8, 3>, grid, dim3(512), 0, st, p);
+      else if (bm == 128) vg_launch_timed(igemm_kernel<MODE, 128, 64, 4, B_MC, 4, 4, PREC_F32, 8, 3>, grid, dim3(512), 0, st, p);
+      else vg_launch_timed(igemm_kernel<MODE, 64, 128, 2, B_MC, 4, 4, PREC_F32, 8, 3>, grid, dim3(512), 0, st, p);
+      return 0;
+    }
+    return -3;
+  }
   if (igemm_waves(bm, bn, va, vb, prec) == 8 && p.stats) {
     if constexpr (MODE != MODE_WGRAD) {
       if (p.bx) {

@@ -89,6 +89,7 @@ SIGNATURES = {
     "vg_conv2d_dgrad_bnstats": (c_int, [_P, _P, _P, _P, _P, _P, c_size_t, _P, _P]),
     "vg_conv2d_fwd_bnbwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_float, _P, c_size_t, _P, _P]),
     "vg_conv2d_dgrad_bnbwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_float, _P, c_size_t, _P, _P]),
+    "vg_conv2d_dgrad_actmask": (c_int, [_P, _P, _P, _P, _P, c_int, c_float, _P, _P]),
     "vg_bn_bwd_sums_from_conv": (c_int, [c_int, _P, _P, _P, _P]),
     "vg_bn_stats_from_conv": (c_int, [c_int, _P, _P, c_float, c_float, _P, _P, _P, _P, _P, _P]),
     "vg_bn_apply": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_float, _P]),

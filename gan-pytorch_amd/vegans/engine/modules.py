@@ -136,8 +136,12 @@ class HipSequential(nn.Sequential):
     def forward(self, x):
         mods = list(self._modules.values())
         i, n = 0, len(mods)
+        handed = None        # (act, slope, token): x is a fused activation's output that only mods[i] will see
         while i < n:
             m = mods[i]
+            if handed is not None:
+                ops.act_grad.private_input(x, *handed)
+                handed = None
             fused = _fused_act(m, mods[i + 1]) if i + 1 < n else None
             if i + 1 < n and _wants_stats(m, mods[i + 1]):
                 # the norm behind this convolution takes its batch statistics from the convolution's epilogue
@@ -145,13 +149,28 @@ class HipSequential(nn.Sequential):
                 x = m(x)
                 ops.norm_stats.cancel()
                 i += 1
-                continue
-            if fused is not None:
+            elif fused is not None:
+                # conv + activation in front of another convolution: that one's backward can carry its input gradient
+                # through the activation's slope mask in its own kernel
+                pair = (type(m) is HipConv2d and i + 2 < n and type(mods[i + 2]) is HipConv2d
+                        and not _has_hooks(mods[i + 2]) and torch.is_grad_enabled())
+                if pair:
+                    ops.act_grad.announce()
                 x = m(x, fused[0], fused[1])
+                token = ops.act_grad.withdraw()
+                if token is not None:
+                    handed = (fused[0], fused[1], token)
                 i += 2
             else:
+                if (type(m) in (HipReLU, HipLeakyReLU) and i + 1 < n and type(mods[i + 1]) is HipConv2d and x.dim() == 4
+                        and not _has_hooks(m) and not _has_hooks(mods[i + 1]) and torch.is_grad_enabled()):
+                    ops.act_grad.announce()
                 x = m(x)
+                token = ops.act_grad.withdraw()
+                if token is not None:
+                    handed = ((_hip.ACT_RELU, 0.0) if type(m) is HipReLU else (_hip.ACT_LRELU, m.negative_slope)) + (token,)
                 i += 1
+            ops.act_grad.cancel()
         return x
 
 

@@ -408,6 +408,54 @@ class _NormBackwardSums:
 norm_bwd = _NormBackwardSums()
 
 
+class _ActivationGradient:
+    """Agreement between two neighbouring layers of a container, conv_a (+ ReLU / LeakyReLU in its epilogue) -> conv_b,
+    whose intermediate activation no one else sees: conv_b's backward returns its input gradient ALREADY multiplied by
+    the activation's slope mask (in the epilogue of its input-gradient kernel where there is such a kernel, with the
+    separate mask kernel otherwise), and conv_a's backward then skips its own mask pass. The container announces the
+    pairing before it runs conv_a (`announce`); conv_a's operator, if it is the fused kind, takes a token
+    (`take_token`); the container then hands conv_b the activation (`private_input`), and conv_b's operator marks the
+    token when it has accepted (`take_input`). conv_a's backward skips the mask only when the token is marked, so a
+    consumer that never accepted leaves everything as it was."""
+
+    def __init__(self):
+        self.announced = False
+        self.token = None
+        self.pending = None      # (activation tensor, act, slope, token)
+
+    def announce(self):
+        self.announced, self.token = True, None
+
+    def take_token(self):
+        if not self.announced or _precision != 0:
+            return None
+        self.announced = False
+        self.token = {"accepted": False}
+        return self.token
+
+    def withdraw(self):
+        """End of conv_a's call: the token its operator took, if any."""
+        self.announced = False
+        token, self.token = self.token, None
+        return token
+
+    def private_input(self, y, act, slope, token):
+        self.pending = (y, act, slope, token)
+
+    def take_input(self, x):
+        pending, self.pending = self.pending, None
+        if pending is None or pending[0].data_ptr() != x.data_ptr() or pending[0].shape != x.shape:
+            return None
+        pending[3]["accepted"] = True
+        return pending[1], pending[2]
+
+    def cancel(self):
+        self.pending = None
+
+
+act_grad = _ActivationGradient()
+
+
 def _conv_with_stats(mode, g, args, out, src=None):
     """Run the convolution through an entry point whose epilogue also leaves per-tile column sums: the batch statistics
     of the output (src None), or the backward sums of the norm `src` whose output gradient `out` is. True when the
@@ -532,6 +580,16 @@ def _wants_input_grad(ctx, x):
     return not (grads.collecting() and getattr(x, "_vg_no_grad_sink", False))
 
 
+def _input_gradient(ctx, gy, w, x, g, lab):
+    """Input gradient of a convolution operator whose forward noted what its input is (ctx.norm_src, ctx.input_act)."""
+    if ctx.input_act is not None:
+        return ConvDgradMaskFn.apply(gy, w, x, g, ctx.input_act[0], ctx.input_act[1], lab + (0,))
+    norm_bwd.request(ctx.norm_src)
+    gx = ConvDgradFn.apply(gy, w, None, g, lab + (0,))
+    norm_bwd.cancel()
+    return gx
+
+
 class ConvFwdFn(Function):
     @staticmethod
     def forward(ctx, x, w, bias, g, label=None):
@@ -540,6 +598,7 @@ class ConvFwdFn(Function):
         ctx.label = _label(label)
         ctx.save_for_backward(x, w, bias)
         ctx.norm_src = norm_bwd.source_of(x)     # x is the output of a training-mode norm: see _NormBackwardSums
+        ctx.input_act = act_grad.take_input(x)   # x is a private ReLU / LeakyReLU output: see _ActivationGradient
         return raw_conv_fwd(g, x, w, bias)
 
     @staticmethod
@@ -549,9 +608,7 @@ class ConvFwdFn(Function):
         params = not inputs_only.active
         gx = None
         if _wants_input_grad(ctx, x):
-            norm_bwd.request(ctx.norm_src)
-            gx = ConvDgradFn.apply(gy, w, None, g, lab + (0,))
-            norm_bwd.cancel()
+            gx = _input_gradient(ctx, gy, w, x, g, lab)
         gw = ConvWgradFn.apply(gy, x, g, tuple(w.shape), lab + (1,)) if (params and ctx.needs_input_grad[1]) else None
         gb = ColSumFn.apply(gy) if (params and bias is not None and ctx.needs_input_grad[2]) else None
         return gx, grads.route(w, lab, gw), grads.route(bias, lab, gb), None, None
@@ -573,6 +630,9 @@ class ConvActFn(Function):
                                         act, c_float(slope), _stream()))
         ctx.g, ctx.act, ctx.slope = g, act, slope
         ctx.label = grads.ticket()
+        ctx.norm_src = norm_bwd.source_of(x)
+        ctx.input_act = act_grad.take_input(x)
+        ctx.consumer = act_grad.take_token()     # the layer behind may return its input gradient already masked
         ctx.save_for_backward(x, w, bias, y)
         return y
 
@@ -580,9 +640,10 @@ class ConvActFn(Function):
     def backward(ctx, gy):
         x, w, bias, y = ctx.saved_tensors
         g, lab = ctx.g, ctx.label
-        gpre = ActBwdFn.apply(gy, y, ctx.act, ctx.slope)
+        masked = ctx.consumer is not None and ctx.consumer["accepted"]
+        gpre = gy if masked else ActBwdFn.apply(gy, y, ctx.act, ctx.slope)
         params = not inputs_only.active
-        gx = ConvDgradFn.apply(gpre, w, None, g, lab + (0,)) if _wants_input_grad(ctx, x) else None
+        gx = _input_gradient(ctx, gpre, w, x, g, lab) if _wants_input_grad(ctx, x) else None
         gw = ConvWgradFn.apply(gpre, x, g, tuple(w.shape), lab + (1,)) if (params and ctx.needs_input_grad[1]) else None
         gb = ColSumFn.apply(gpre) if (params and bias is not None and ctx.needs_input_grad[2]) else None
         return gx, grads.route(w, lab, gw), grads.route(bias, lab, gb), None, None, None
@@ -612,6 +673,45 @@ class ConvDgradFn(Function):
         d_w = ConvWgradFn.apply(gy, ggx, g, tuple(w.shape), lab + (1,)) if (params and ctx.needs_input_grad[1]) else None
         d_b = ColSumFn.apply(ggx) if (params and bias is not None and ctx.needs_input_grad[2]) else None
         return d_gy, grads.route(w, lab, d_w), grads.route(bias, lab, d_b), None, None
+
+
+class ConvDgradMaskFn(Function):
+    """gx = act'(ref) * conv_transpose(gy, w): the input gradient of a convolution whose input `ref` is the output of a
+    ReLU / LeakyReLU, carried on to the front of that activation. The mask is applied in the contraction kernel's
+    epilogue where the geometry has such a kernel, by the separate mask kernel otherwise."""
+
+    @staticmethod
+    def forward(ctx, gy, w, ref, g, act, slope, label=None):
+        ctx.g, ctx.act, ctx.slope = g, act, slope
+        ctx.label = _label(label)
+        ctx.save_for_backward(gy, w, ref)
+        gy_m, w_m, ref_m = to_nhwc(gy), _weight_mem(w), to_nhwc(ref)
+        _check_shape(gy_m, g.y_shape(), "conv output-side tensor")
+        _check_shape(ref_m, g.x_shape(), "activation output")
+        if w_m.numel() != g.w_numel():
+            raise _hip.HipError("weight has %d elements, geometry expects %d" % (w_m.numel(), g.w_numel()))
+        if _precision != 0:
+            gx = raw_conv_dgrad(g, gy, w, None)
+            masked = ctypes.c_int(0)
+        else:
+            gx = _new_act(g.N, g.Ci, g.H, g.W, gy_m, g.flat)
+            masked = ctypes.c_int(0)
+            _launch_conv(1, g, lambda: call("vg_conv2d_dgrad_actmask", ctypes.byref(g.c), _ptr(gy_m), _ptr(w_m), _ptr(gx),
+                                            _ptr(ref_m), act, c_float(slope), ctypes.byref(masked), _stream()))
+        if not masked.value:
+            plain, gx = gx, torch.empty_like(gx)
+            call("vg_act_bwd", _ptr(plain), _ptr(ref_m), _ptr(gx), c_size_t(gx.numel()), act, c_float(slope), _stream())
+        return gx
+
+    @staticmethod
+    def backward(ctx, ggx):
+        gy, w, ref = ctx.saved_tensors
+        g, lab = ctx.g, ctx.label
+        params = not inputs_only.active
+        m = ActBwdFn.apply(ggx, ref, ctx.act, ctx.slope)
+        d_gy = ConvFwdFn.apply(m, w, None, g, lab + (0,)) if _wants_input_grad(ctx, gy) else None
+        d_w = ConvWgradFn.apply(gy, m, g, tuple(w.shape), lab + (1,)) if (params and ctx.needs_input_grad[1]) else None
+        return d_gy, grads.route(w, lab, d_w), None, None, None, None, None
 
 
 class ConvWgradFn(Function):
@@ -919,12 +1019,16 @@ class ActFn(Function):
         y = torch.empty_like(x)
         call("vg_act_fwd", _ptr(x), _ptr(y), c_size_t(x.numel()), act, c_float(slope), _stream())
         ctx.act, ctx.slope = act, slope
+        # ReLU / LeakyReLU in front of a convolution that may return its input gradient already masked
+        ctx.consumer = act_grad.take_token() if act in (_hip.ACT_RELU, _hip.ACT_LRELU) and slope >= 0 else None
         ctx.save_for_backward(y if act in _SAVES_OUTPUT else x_in)
         return y
 
     @staticmethod
     def backward(ctx, gy):
         (ref,) = ctx.saved_tensors
+        if ctx.consumer is not None and ctx.consumer["accepted"]:
+            return gy, None, None
         return ActBwdFn.apply(gy, ref, ctx.act, ctx.slope), None, None
 
 

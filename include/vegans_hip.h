@@ -227,6 +227,14 @@ int vg_bn_bwd_reduce(const float* gy, const float* x, const float* mean, const f
 int vg_bn_bwd_apply(const float* gy, const float* x, const float* mean, const float* invstd,
                     const float* gamma, const float* sums, float* gx, int M, int C, const float* act_out, int act,
                     float slope, const float* beta, void* stream);
+/* vg_conv2d_dgrad followed by the backward of a ReLU / LeakyReLU that sits in FRONT of the convolution (layer order
+ * conv_a -> act -> conv_b; this is conv_b's input gradient): gx = act'(act_out) * conv_transpose(gy, w), the mask
+ * applied in the kernel's epilogue, so the gradient behind the activation is never written. act_out is the activation's
+ * output (conv_b's input), laid out like gx. *masked is 1 when the geometry ran on a kernel with this epilogue (the
+ * eight-wave f32 MFMA tiles); 0 means gx holds the plain input gradient and the caller applies vg_act_bwd itself.
+ * Reference: autograd through nn.LeakyReLU between two nn.Conv2d (examples/example_input_formats.py:64-77). */
+int vg_conv2d_dgrad_actmask(const vg_conv_geom* g, const float* gy, const float* w, float* gx, const float* act_out,
+                            int act, float slope, int* masked, void* stream);
 /* The two sums of vg_bn_bwd_reduce without a pass over (gy, x): when the gradient that arrives at a BatchNorm's output
  * is itself the output of a convolution kernel (the input gradient of the Conv2d behind the norm: vg_conv2d_dgrad_bnbwd;
  * the input gradient of a ConvTranspose2d behind it, which is a forward convolution: vg_conv2d_fwd_bnbwd), that kernel's

@@ -957,3 +957,60 @@ def test_norm_backward_sums_are_not_taken_when_the_gradient_was_summed(gpu):
     assert seen == [None]
     for name, a, w in zip(("gx", "ggamma", "gbeta"), got, want):
         _close(a, w, 3e-5, "%s vs torch float64" % name)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("layers,in_shape", [
+    # image stem with LeakyReLU in its epilogue, in front of a strided convolution served by the eight-wave tiles
+    (lambda nn: [nn.Conv2d(3, 64, 4, 2, 1), nn.LeakyReLU(0.2), nn.Conv2d(64, 128, 4, 2, 1)], (32, 3, 32, 32)),
+    # small second convolution: no kernel with the mask epilogue, the separate mask kernel runs inside its backward
+    (lambda nn: [nn.Conv2d(3, 16, 4, 2, 1), nn.ReLU(), nn.Conv2d(16, 8, 3, 1, 1)], (4, 3, 16, 16)),
+    # activation as an operator of its own (no fused convolution kernel for this geometry)
+    (lambda nn: [nn.Conv2d(64, 64, 3, 1, 1), nn.LeakyReLU(0.2), nn.Conv2d(64, 128, 4, 2, 1)], (16, 64, 16, 16)),
+    # two pairs in a row, ragged tiles, a norm behind the last convolution
+    (lambda nn: [nn.Conv2d(3, 64, 4, 2, 1), nn.LeakyReLU(0.2), nn.Conv2d(64, 128, 3, 1, 1), nn.ReLU(),
+                 nn.Conv2d(128, 64, 4, 2, 1, bias=False), nn.BatchNorm2d(64), nn.LeakyReLU(0.2)], (9, 3, 26, 22)),
+])
+def test_activation_gradient_carried_by_the_next_convolutions_input_gradient(gpu, layers, in_shape):
+    """conv -> ReLU / LeakyReLU -> conv inside a Sequential: the second convolution's backward returns its input
+    gradient already multiplied by the activation's slope mask and the activation's own backward pass is skipped.
+    First- and second-order gradients (gradient-penalty shaped) must equal, bit for bit, those of the separate mask
+    pass, and agree with torch in float64."""
+    import copy
+    from torch import nn
+    from vegans.engine import modules, ops
+    torch.manual_seed(5)
+    ref = nn.Sequential(*layers(nn))
+    x = torch.randn(*in_shape)
+    probe = torch.randn_like(ref(x))
+    probe2 = torch.rand(*in_shape) + 0.5
+
+    def run(net, xin, probe, probe2):
+        xin = xin.clone().requires_grad_(True)
+        out = net(xin)
+        (gx,) = torch.autograd.grad((out * probe).sum(), xin, create_graph=True)
+        ((gx * gx * probe2).sum() + (out * probe).sum()).backward()
+        return [gx.detach().double().cpu(), xin.grad.double().cpu()] + [q.grad.double().cpu() for q in net.parameters()]
+
+    want = run(copy.deepcopy(ref).double(), x.double(), probe.double(), probe2.double())
+    outs = {}
+    for carried in (True, False):
+        net = copy.deepcopy(ref).to("cuda")
+        modules.bind(net)
+        modules.prepare_parameters(net)
+        net.train()
+        accepted = []
+        orig_take, orig_announce = ops.act_grad.take_input, ops.act_grad.announce
+        ops.act_grad.take_input = lambda t: accepted.append(orig_take(t)) or accepted[-1]
+        if not carried:
+            ops.act_grad.announce = lambda: None
+        try:
+            outs[carried] = run(net, x.to("cuda"), probe.to("cuda"), probe2.to("cuda"))
+        finally:
+            ops.act_grad.take_input, ops.act_grad.announce = orig_take, orig_announce
+        pairs = sum(1 for a in accepted if a is not None)
+        assert pairs == (sum(isinstance(m, (nn.ReLU, nn.LeakyReLU)) and i + 1 < len(ref) and isinstance(ref[i + 1], nn.Conv2d)
+                             for i, m in enumerate(ref)) if carried else 0)
+    for k, (a, b, w) in enumerate(zip(outs[True], outs[False], want)):
+        assert torch.equal(a, b), ("tensor %d differs between the two backward forms" % k, float((a - b).abs().max()))
+        _close(a, w, 5e-5, "tensor %d vs torch float64" % k)
