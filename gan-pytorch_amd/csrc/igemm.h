@@ -703,6 +703,47 @@ __global__ void __launch_bounds__(NW * 64, NW == 8 ? 4 : 1) igemm_kernel(const I
     mma_frags(afy, bfy);
   };
 
+  // element offset of row `row` of this block's row space in the output tensor (NO_ROW past the last row); in the
+  // input-gradient mode the rows are the pixels of one parity class, scattered over the output image
+  constexpr unsigned NO_ROW = 0xffffffffu;      // offsets stay below 2^31 (tensor size limit of the geometry check)
+  auto out_row_offset = [&](int row) -> unsigned {
+    if (row >= M) return NO_ROW;
+    if constexpr (MODE == MODE_DGRAD) {
+      const int n = vg_div_row(row, plane, inv_plane, fast), rem = row - n * plane;
+      const int ii = vg_div_row(rem, roww, inv_roww, fast), jj = rem - ii * roww;
+      return (unsigned)((n * p.H + ii * p.sh + off_h) * p.W + jj * p.sw + off_w) * (unsigned)p.Ncols;
+    } else {
+      return (unsigned)row * (unsigned)p.Ncols;
+    }
+  };
+  // STATS = 2, 3: the block's tile of the side tensor bx (laid out like the output) is fetched with 16-byte loads (rows
+  // whole, four columns a thread) issued one at a time early in the k-walk, where they travel with the operand tiles
+  // and nothing waits for them on their own; the epilogue hands them round through LDS (STATS = 3 keeps one bit per
+  // element, value > 0, and shrinks the values to that right after the walk).
+  constexpr bool SIDE = (STATS == 3 && MODE == MODE_DGRAD) || (STATS == 2 && MODE != MODE_WGRAD);
+  constexpr int SIDE_C4 = BN / 4, SIDE_PER = SIDE ? BM * SIDE_C4 / NT : 1;
+  // (the largest tile has no registers to carry the values through the walk: it reads them in the epilogue)
+  constexpr bool SIDE_EARLY = SIDE && SIDE_PER <= 4;
+  unsigned mask_bits = 0;
+  float4 side_rv[SIDE_PER];
+  auto fetch_side_one = [&](int k, auto&& row_offset_of) {
+    const int idx = tid + k * NT, rr = idx / SIDE_C4, col = n0 + (idx - rr * SIDE_C4) * 4;
+    const unsigned o = row_offset_of(rr);
+    side_rv[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (o != NO_ROW && col < p.Ncols) side_rv[k] = *reinterpret_cast<const float4*>(p.bx + (size_t)o + col);
+  };
+  auto fetch_side = [&](auto&& row_offset_of) {
+#pragma unroll
+    for (int k = 0; k < SIDE_PER; ++k) fetch_side_one(k, row_offset_of);
+  };
+  auto early_row = [&](int rr) { return out_row_offset(m0 + rr); };
+  auto pack_mask = [&]() {
+#pragma unroll
+    for (int k = 0; k < SIDE_PER; ++k)
+      mask_bits |= (unsigned)((side_rv[k].x > 0.f ? 1 : 0) | (side_rv[k].y > 0.f ? 2 : 0) | (side_rv[k].z > 0.f ? 4 : 0) |
+                              (side_rv[k].w > 0.f ? 8 : 0)) << (4 * k);
+  };
+  static_assert(!SIDE || (BM * SIDE_C4 % NT == 0 && SIDE_PER <= 8), "tile not a multiple of the block");
   if (nk > 0) {
     point_tiles();
     fetch_tiles();
@@ -715,10 +756,19 @@ __global__ void __launch_bounds__(NW * 64, NW == 8 ? 4 : 1) igemm_kernel(const I
 
   int kt = 0;
   for (; kt + 1 < nk; kt += 2) {
+    if constexpr (SIDE_EARLY) {      // one 16-byte load of the side tile every other k-step
+#pragma unroll
+      for (int k = 0; k < SIDE_PER; ++k)
+        if (kt == 2 * k) fetch_side_one(k, early_row);
+    }
     k_step(0);
     k_step(1);
   }
   if (kt < nk) k_step(0);
+  if constexpr (SIDE_EARLY) {
+    if (nk < 2 * SIDE_PER) fetch_side(early_row);      // a k-walk too short to have issued them all
+    if constexpr (STATS == 3) pack_mask();
+  }
 
   // ---- epilogue: lane holds column (lane&31) and rows (e&3)+8*(e>>2)+4*(lane>>5) of each 32x32 tile ----
   float* outp = p.out;
@@ -802,26 +852,34 @@ __global__ void __launch_bounds__(NW * 64, NW == 8 ? 4 : 1) igemm_kernel(const I
   // dgrad: the rows of a tile are pixels of one parity class, scattered over the output image. Each row's element
   // offset is worked out once per block (two divisions per row) and left in LDS, which the k loop no longer needs,
   // instead of thirty-two times per lane inside the store loop.
-  constexpr unsigned NO_ROW = 0xffffffffu;      // offsets stay below 2^31 (tensor size limit of the geometry check)
   unsigned* row_off = reinterpret_cast<unsigned*>(smem);
   if constexpr (MODE == MODE_DGRAD) {
     __syncthreads();                            // every wave is done with the staged tiles
-    for (int rr = tid; rr < BM; rr += NT) {
-      const int row = m0 + rr;
-      unsigned off = NO_ROW;
-      if (row < M) {
-        const int n = vg_div_row(row, plane, inv_plane, fast), rem = row - n * plane;
-        const int ii = vg_div_row(rem, roww, inv_roww, fast), jj = rem - ii * roww;
-        off = (unsigned)((n * p.H + ii * p.sh + off_h) * p.W + jj * p.sw + off_w) * (unsigned)p.Ncols;
-      }
-      row_off[rr] = off;
+    for (int rr = tid; rr < BM; rr += NT) row_off[rr] = out_row_offset(m0 + rr);
+    if constexpr (STATS == 3 && !SIDE_EARLY) {
+      __syncthreads();
+      fetch_side([&](int rr) { return row_off[rr]; });
+      pack_mask();
+    }
+    if constexpr (STATS == 3) {
+      unsigned char* mbits = reinterpret_cast<unsigned char*>(smem + BM);      // [BM][BN / 4], behind the row offsets
+#pragma unroll
+      for (int k = 0; k < SIDE_PER; ++k) mbits[tid + k * NT] = (unsigned char)((mask_bits >> (4 * k)) & 15u);
     }
     __syncthreads();
   }
-  if constexpr (STATS == 2) {
+  if constexpr (STATS == 2 && MODE != MODE_WGRAD) {
     const int tile = (MODE == MODE_DGRAD) ? zz * p.mtiles + mt : mt;
-    float* part = smem + BM;          // [WAVES_M][BN][2], behind the row offsets
+    constexpr int LDX = BN + 4;
+    static_assert(BM + BM * LDX <= 2 * BUF && 2 * WAVES_M * BN <= BM * LDX, "the staging buffers cannot hold the side tile");
+    float* xt = smem + BM;            // the block's tile of the norm's input, [BM][LDX], behind the row offsets
     if constexpr (MODE != MODE_DGRAD) __syncthreads();       // every wave is done with the staged tiles
+    if constexpr (!SIDE_EARLY) fetch_side([&](int rr) { return MODE == MODE_DGRAD ? row_off[rr] : out_row_offset(m0 + rr); });
+#pragma unroll
+    for (int k = 0; k < SIDE_PER; ++k) {
+      const int idx = tid + k * NT, rr = idx / SIDE_C4;
+      *reinterpret_cast<float4*>(&xt[rr * LDX + (idx - rr * SIDE_C4) * 4]) = side_rv[k];
+    }
     float mu[TN], rs[TN], ga[TN], be[TN], s1[TN], s2[TN];
 #pragma unroll
     for (int ni = 0; ni < TN; ++ni) {
@@ -834,47 +892,30 @@ __global__ void __launch_bounds__(NW * 64, NW == 8 ? 4 : 1) igemm_kernel(const I
         if (p.bbeta) be[ni] = p.bbeta[col];
       }
     }
-    const float* xcol = p.bx + n0 + wn * TN * 32 + r;
+    __syncthreads();
 #pragma unroll
     for (int mi = 0; mi < TM; ++mi) {
-      const int row_t = m0 + (wm * TM + mi) * 32 + 4 * h;
-      // all of the tile's x values first (the loads must not queue behind the stores further down), then the sums
-      float xv[16][TN];
-      unsigned ok_rows = 0;
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
-        const int dr = (e & 3) + 8 * (e >> 2);
-        size_t off;
-        bool ok;
-        if constexpr (MODE == MODE_DGRAD) {
-          const unsigned o = row_off[(wm * TM + mi) * 32 + 4 * h + dr];
-          ok = o != NO_ROW;
-          off = o;
-        } else {
-          ok = row_t + dr < M;
-          off = (size_t)(row_t + dr) * p.Ncols;
-        }
-        ok_rows |= ok ? (1u << e) : 0u;
-#pragma unroll
-        for (int ni = 0; ni < TN; ++ni) xv[e][ni] = (ok && cok[ni]) ? xcol[off + ni * 32] : 0.f;
-      }
-#pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        if (ok_rows & (1u << e)) {
+        const int rr = (wm * TM + mi) * 32 + 4 * h + (e & 3) + 8 * (e >> 2);
+        if (m0 + rr < M) {
 #pragma unroll
           for (int ni = 0; ni < TN; ++ni) {
             if (cok[ni]) {
+              const float xv = xt[rr * LDX + (wn * TN + ni) * 32 + r];
               float g = acc[mi][ni][e];
               if (has_bias) g += bcol[ni];
               if (p.bact != VG_ACT_NONE)
-                g *= vg_mask_grad(vg_bn_affine(xv[e][ni], mu[ni], rs[ni], p.bgamma, ga[ni], p.bbeta, be[ni]), p.bact, p.bslope);
+                g *= vg_mask_grad(vg_bn_affine(xv, mu[ni], rs[ni], p.bgamma, ga[ni], p.bbeta, be[ni]), p.bact, p.bslope);
               s1[ni] += g;
-              s2[ni] = fmaf(g, (xv[e][ni] - mu[ni]) * rs[ni], s2[ni]);
+              s2[ni] = fmaf(g, (xv - mu[ni]) * rs[ni], s2[ni]);
             }
           }
         }
       }
     }
+    __syncthreads();                  // the tile has been read: its space takes the waves' partial sums
+    float* part = xt;                 // [WAVES_M][BN][2]
 #pragma unroll
     for (int ni = 0; ni < TN; ++ni) {
       s1[ni] += __shfl_xor(s1[ni], 32, 64);
@@ -899,24 +940,22 @@ __global__ void __launch_bounds__(NW * 64, NW == 8 ? 4 : 1) igemm_kernel(const I
     if (tid == 0 && nt == 0) p.stats[(size_t)p.stats_tiles * 2 * p.Ncols + tile] = (double)min(BM, M - m0);
   }
   if constexpr (STATS == 3 && MODE == MODE_DGRAD) {
-    // the output is a gradient arriving at the output of a ReLU / LeakyReLU whose result bx holds (laid out like the
-    // output): multiply by the activation's slope at each position, so what is stored is the gradient in front of it
-    const float* rcol = p.bx + n0 + wn * TN * 32 + r;
+    // The output is a gradient arriving at the output of a ReLU / LeakyReLU (bx): multiply by the activation's slope at
+    // each position, so what is stored is the gradient in front of it. Every lane picks, from the bits left in LDS
+    // above, those of the elements its accumulators hold.
+    const unsigned char* mbits = reinterpret_cast<const unsigned char*>(smem + BM);
+    const float low = p.bact == VG_ACT_RELU ? 0.f : p.bslope;
 #pragma unroll
     for (int mi = 0; mi < TM; ++mi) {
-      float rv[16][TN];
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
-        const unsigned o = row_off[(wm * TM + mi) * 32 + 4 * h + (e & 3) + 8 * (e >> 2)];
-#pragma unroll
-        for (int ni = 0; ni < TN; ++ni) rv[e][ni] = (o != NO_ROW && cok[ni]) ? rcol[(size_t)o + ni * 32] : 1.f;
-      }
-#pragma unroll
-      for (int e = 0; e < 16; ++e) {
+        const int rr = (wm * TM + mi) * 32 + 4 * h + (e & 3) + 8 * (e >> 2);
 #pragma unroll
         for (int ni = 0; ni < TN; ++ni) {
+          const int c = (wn * TN + ni) * 32 + r;
+          const bool up = (mbits[rr * SIDE_C4 + (c >> 2)] >> (c & 3)) & 1;
           if (has_bias) acc[mi][ni][e] += bcol[ni];
-          acc[mi][ni][e] *= vg_mask_grad(rv[e][ni], p.bact, p.bslope);
+          acc[mi][ni][e] *= up ? 1.f : low;
         }
       }
     }

@@ -963,6 +963,8 @@ def test_norm_backward_sums_are_not_taken_when_the_gradient_was_summed(gpu):
 @pytest.mark.parametrize("layers,in_shape", [
     # image stem with LeakyReLU in its epilogue, in front of a strided convolution served by the eight-wave tiles
     (lambda nn: [nn.Conv2d(3, 64, 4, 2, 1), nn.LeakyReLU(0.2), nn.Conv2d(64, 128, 4, 2, 1)], (32, 3, 32, 32)),
+    # 128 channels in between: the 128 x 128 tile, which reads the activation in its epilogue
+    (lambda nn: [nn.Conv2d(3, 128, 4, 2, 1), nn.LeakyReLU(0.2), nn.Conv2d(128, 128, 4, 2, 1)], (64, 3, 32, 32)),
     # small second convolution: no kernel with the mask epilogue, the separate mask kernel runs inside its backward
     (lambda nn: [nn.Conv2d(3, 16, 4, 2, 1), nn.ReLU(), nn.Conv2d(16, 8, 3, 1, 1)], (4, 3, 16, 16)),
     # activation as an operator of its own (no fused convolution kernel for this geometry)
