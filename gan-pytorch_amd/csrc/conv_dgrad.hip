@@ -14,7 +14,8 @@ extern "C" int vg_conv2d_dgrad(const vg_conv_geom* g, const float* gy, const flo
 
 static int conv_dgrad_impl(const vg_conv_geom* g, const float* gy, const float* w, const float* bias, float* gx,
                            int precision, void* workspace, size_t workspace_bytes, const void* gy_planes,
-                           const void* w_planes, double* stats, int* stats_written, const VgNormBwdSrc* nb, void* stream);
+                           const void* w_planes, double* stats, int* stats_written, const VgNormBwdSrc* nb, void* stream,
+                           bool io_h = false);
 int vg_check_norm_bwd_src(const VgNormBwdSrc* nb, const void* stats, size_t stats_bytes, size_t need, const int* written,
                           const char* who);
 
@@ -53,9 +54,19 @@ extern "C" int vg_conv2d_dgrad_actmask(const vg_conv_geom* g, const float* gy, c
   return conv_dgrad_impl(g, gy, w, nullptr, gx, VG_PREC_F32, nullptr, 0, nullptr, nullptr, nullptr, masked, &nb, stream);
 }
 
+extern "C" int vg_conv2d_dgrad_h(const vg_conv_geom* g, const void* gy, const void* w, const float* bias, void* gx,
+                                 void* stream) {
+  if (!vg_conv2d_h_applies(1, g))
+    return vg_fail(VG_ERR_INVALID, "vg_conv2d_dgrad_h: this geometry is not served on bf16 tensors (vg_conv2d_h_applies)");
+  VG_REQUIRE(gy && w && gx && vg_aligned16(gy) && vg_aligned16(w) && vg_aligned16(gx), "vg_conv2d_dgrad_h: null or misaligned tensor");
+  return conv_dgrad_impl(g, (const float*)gy, (const float*)w, bias, (float*)gx, VG_PREC_BF16, nullptr, 0, gy, w, nullptr,
+                         nullptr, nullptr, stream, true);
+}
+
 static int conv_dgrad_impl(const vg_conv_geom* g, const float* gy, const float* w, const float* bias, float* gx,
                            int precision, void* workspace, size_t workspace_bytes, const void* gy_planes,
-                           const void* w_planes, double* stats, int* stats_written, const VgNormBwdSrc* nb, void* stream) {
+                           const void* w_planes, double* stats, int* stats_written, const VgNormBwdSrc* nb, void* stream,
+                           bool io_h) {
   if (stats_written) *stats_written = 0;
   if (int e = vg_check_geom(g, "vg_conv2d_dgrad")) return e;
   if (precision < VG_PREC_F32 || precision > VG_PREC_F32_SPLIT)
@@ -63,13 +74,15 @@ static int conv_dgrad_impl(const vg_conv_geom* g, const float* gy, const float* 
   VG_REQUIRE(gy && w && gx, "vg_conv2d_dgrad: null tensor pointer");
 
   // 1x1 gradient image covering the whole input window: one GEMM [N][Co] x [Co][kh*kw*Ci].
-  if (g->Ho == 1 && g->Wo == 1 && g->ph == 0 && g->pw == 0 && g->H == g->kh && g->W == g->kw)
+  if (!io_h && g->Ho == 1 && g->Wo == 1 && g->ph == 0 && g->pw == 0 && g->H == g->kh && g->W == g->kw)
     return vg_gemm_kn(gy, w, bias, g->Ci, gx, g->N, g->kh * g->kw * g->Ci, g->Co, (hipStream_t)stream, precision);
 
-  if (int r = vg_try_dgrad_thin(g, gy, w, bias, gx, (hipStream_t)stream)) return r < 0 ? r : VG_OK;
+  if (!io_h) {
+    if (int r = vg_try_dgrad_thin(g, gy, w, bias, gx, (hipStream_t)stream)) return r < 0 ? r : VG_OK;
+  }
 
   if (precision == VG_PREC_F32_SPLIT && !vg_planes_applicable(1, g)) precision = VG_PREC_F32;
-  const bool planes = pgemm_serves(precision, 1, g);
+  const bool planes = io_h || pgemm_serves(precision, 1, g);
   IgemmParams p{};
   p.A = gy; p.B = w; p.bias = bias; p.out = gx;
   p.N = g->N; p.H = g->H; p.W = g->W; p.Ci = g->Ci; p.Co = g->Co; p.KH = g->kh; p.KW = g->kw;
@@ -95,8 +108,9 @@ static int conv_dgrad_impl(const vg_conv_geom* g, const float* gy, const float* 
     if (int e = pgemm_prepare(pp, gy, (long long)g->N * g->Ho * g->Wo * g->Co, w, (long long)g->Co * g->kh * g->kw * g->Ci,
                               np, workspace, workspace_bytes, (hipStream_t)stream, "vg_conv2d_dgrad", gy_planes, w_planes))
       return e;
-    if ((np == 3 ? pgemm_launch<MODE_DGRAD, 3>(pp, bm, bn, grid, (hipStream_t)stream)
-                 : pgemm_launch<MODE_DGRAD, 1>(pp, bm, bn, grid, (hipStream_t)stream)) != 0)
+    if ((io_h ? pgemm_launch<MODE_DGRAD, 1, true>(pp, bm, bn, grid, (hipStream_t)stream)
+              : np == 3 ? pgemm_launch<MODE_DGRAD, 3>(pp, bm, bn, grid, (hipStream_t)stream)
+                        : pgemm_launch<MODE_DGRAD, 1>(pp, bm, bn, grid, (hipStream_t)stream)) != 0)
       return vg_fail(VG_ERR_INVALID, "vg_conv2d_dgrad: no plane kernel for tile %dx%d", bm, bn);
     VG_CHECK_LAUNCH("vg_conv2d_dgrad(planes)");
     return VG_OK;

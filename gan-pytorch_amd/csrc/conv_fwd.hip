@@ -43,7 +43,7 @@ static void fwd_tiles(const vg_conv_geom* g, int* bm, int* bn, int* mtiles, int*
 
 static int conv_fwd_impl(const vg_conv_geom* g, const float* x, const float* w, const float* bias, float* y, int precision,
                          void* workspace, size_t workspace_bytes, const void* x_planes, const void* w_planes,
-                         double* stats, int* stats_written, const VgNormBwdSrc* nb, void* stream);
+                         double* stats, int* stats_written, const VgNormBwdSrc* nb, void* stream, bool io_h = false);
 
 extern "C" int vg_conv2d_fwd_prec(const vg_conv_geom* g, const float* x, const float* w, const float* bias,
                                   float* y, int precision, void* workspace, size_t workspace_bytes, const void* x_planes,
@@ -100,14 +100,16 @@ extern "C" int vg_conv2d_fwd_bnbwd(const vg_conv_geom* g, const float* x, const 
 
 static int conv_fwd_impl(const vg_conv_geom* g, const float* x, const float* w, const float* bias, float* y, int precision,
                          void* workspace, size_t workspace_bytes, const void* x_planes, const void* w_planes,
-                         double* stats, int* stats_written, const VgNormBwdSrc* nb, void* stream) {
+                         double* stats, int* stats_written, const VgNormBwdSrc* nb, void* stream, bool io_h) {
   if (stats_written) *stats_written = 0;
   if (int e = vg_check_geom(g, "vg_conv2d_fwd")) return e;
   if (int e = check_precision(precision, "vg_conv2d_fwd")) return e;
   VG_REQUIRE(x && w && y, "vg_conv2d_fwd: null tensor pointer");
-  if (int r = vg_try_fwd_thin(g, x, w, bias, y, (hipStream_t)stream)) return r < 0 ? r : VG_OK;
+  if (!io_h) {
+    if (int r = vg_try_fwd_thin(g, x, w, bias, y, (hipStream_t)stream)) return r < 0 ? r : VG_OK;
+  }
   if (precision == VG_PREC_F32_SPLIT && !vg_planes_applicable(0, g)) precision = VG_PREC_F32;
-  const bool planes = pgemm_serves(precision, 0, g);
+  const bool planes = io_h || pgemm_serves(precision, 0, g);
   IgemmParams p{};
   p.A = x; p.B = w; p.bias = bias; p.out = y;
   p.N = g->N; p.H = g->H; p.W = g->W; p.Ci = g->Ci; p.Co = g->Co; p.KH = g->kh; p.KW = g->kw;
@@ -131,8 +133,9 @@ static int conv_fwd_impl(const vg_conv_geom* g, const float* x, const float* w, 
     if (int e = pgemm_prepare(pp, x, (long long)g->N * g->H * g->W * g->Ci, w, (long long)g->Co * p.Ktot, np, workspace,
                               workspace_bytes, (hipStream_t)stream, "vg_conv2d_fwd", x_planes, w_planes))
       return e;
-    if ((np == 3 ? pgemm_launch<MODE_FWD, 3>(pp, bm, bn, grid, (hipStream_t)stream)
-                 : pgemm_launch<MODE_FWD, 1>(pp, bm, bn, grid, (hipStream_t)stream)) != 0)
+    if ((io_h ? pgemm_launch<MODE_FWD, 1, true>(pp, bm, bn, grid, (hipStream_t)stream)
+              : np == 3 ? pgemm_launch<MODE_FWD, 3>(pp, bm, bn, grid, (hipStream_t)stream)
+                        : pgemm_launch<MODE_FWD, 1>(pp, bm, bn, grid, (hipStream_t)stream)) != 0)
       return vg_fail(VG_ERR_INVALID, "vg_conv2d_fwd: no plane kernel for tile %dx%d", bm, bn);
     VG_CHECK_LAUNCH("vg_conv2d_fwd(planes)");
     return VG_OK;
@@ -155,6 +158,30 @@ static int conv_fwd_impl(const vg_conv_geom* g, const float* x, const float* w, 
     return vg_fail(VG_ERR_INVALID, "vg_conv2d_fwd: no kernel variant for bn=%d va=%d vb=%d", bn, va, vb);
   VG_CHECK_LAUNCH("vg_conv2d_fwd");
   return VG_OK;
+}
+
+// ---- activations stored as bf16 --------------------------------------------------------------------------------------
+// Which contractions run entirely on bf16 tensors (operands read as they lie in memory, result written as bf16; the
+// weight gradient leaves as f32): the shapes the plane GEMM serves, minus those the library routes to special kernels
+// (thin layers, image stems, the 1x1 latent GEMM), which a caller runs through the f32 entry points on converted copies.
+bool vg_wgrad_narrow_tile(const vg_conv_geom* g);   // conv_wgrad.hip: the 32-column plan the plane GEMM has no tile for
+
+extern "C" int vg_conv2d_h_applies(int mode, const vg_conv_geom* g) {
+  if (vg_check_geom(g, "vg_conv2d_h_applies") || mode < 0 || mode > 2) return 0;
+  if (!vg_planes_applicable(mode, g)) return 0;          // channel counts in multiples of 8, more than 32 columns
+  if (g->Co <= 4 || g->Ci <= 4 || vg_stem_fwd_applies(g) || vg_thin_dgrad_applies(g)) return 0;
+  if (mode == 1 && g->Ho == 1 && g->Wo == 1 && g->ph == 0 && g->pw == 0 && g->H == g->kh && g->W == g->kw) return 0;
+  if (mode == 2 && vg_wgrad_narrow_tile(g)) return 0;
+  return 1;
+}
+
+extern "C" int vg_conv2d_fwd_h(const vg_conv_geom* g, const void* x, const void* w, const float* bias, void* y,
+                               void* stream) {
+  if (!vg_conv2d_h_applies(0, g))
+    return vg_fail(VG_ERR_INVALID, "vg_conv2d_fwd_h: this geometry is not served on bf16 tensors (vg_conv2d_h_applies)");
+  VG_REQUIRE(x && w && y && vg_aligned16(x) && vg_aligned16(w) && vg_aligned16(y), "vg_conv2d_fwd_h: null or misaligned tensor");
+  return conv_fwd_impl(g, (const float*)x, (const float*)w, bias, (float*)y, VG_PREC_BF16, nullptr, 0, x, w, nullptr, nullptr,
+                       nullptr, stream, true);
 }
 
 // Tiles and rows of the statistics vg_conv2d_fwd_bnstats / vg_conv2d_dgrad_bnstats left for this geometry.

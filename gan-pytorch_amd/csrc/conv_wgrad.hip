@@ -110,6 +110,8 @@ int launch_slab_reduce(const float* slabs, float* out, size_t count, int nsplit,
 
 }  // namespace
 
+bool vg_wgrad_narrow_tile(const vg_conv_geom* g) { return wgrad_plan(g).bn == 32; }
+
 extern "C" size_t vg_conv2d_wgrad_workspace_bytes(const vg_conv_geom* g) {
   if (vg_check_geom(g, "vg_conv2d_wgrad_workspace_bytes")) return 0;
   const WgradPlan pl = wgrad_plan(g);
@@ -142,9 +144,29 @@ extern "C" int vg_conv2d_wgrad_partial(const vg_conv_geom* g, const float* gy, c
   return vg_conv2d_wgrad_partial_prec(g, gy, x, gw, workspace, workspace_bytes, VG_PREC_F32, nullptr, nullptr, stream);
 }
 
+static int wgrad_partial_impl(const vg_conv_geom* g, const float* gy, const float* x, float* gw, void* workspace,
+                              size_t workspace_bytes, int precision, const void* gy_planes, const void* x_planes,
+                              void* stream, bool io_h);
+
 extern "C" int vg_conv2d_wgrad_partial_prec(const vg_conv_geom* g, const float* gy, const float* x, float* gw,
                                             void* workspace, size_t workspace_bytes, int precision, const void* gy_planes,
                                             const void* x_planes, void* stream) {
+  return wgrad_partial_impl(g, gy, x, gw, workspace, workspace_bytes, precision, gy_planes, x_planes, stream, false);
+}
+
+// gy and x stored as bf16, gw f32: the contraction reads the tensors as they lie in memory; split-K slabs (f32) in
+// `workspace` (vg_conv2d_wgrad_workspace_bytes), added by vg_conv2d_wgrad_reduce.
+extern "C" int vg_conv2d_wgrad_partial_h(const vg_conv_geom* g, const void* gy, const void* x, float* gw, void* workspace,
+                                         size_t workspace_bytes, void* stream) {
+  if (!vg_conv2d_h_applies(2, g))
+    return vg_fail(VG_ERR_INVALID, "vg_conv2d_wgrad_partial_h: this geometry is not served on bf16 tensors (vg_conv2d_h_applies)");
+  VG_REQUIRE(gy && x && vg_aligned16(gy) && vg_aligned16(x), "vg_conv2d_wgrad_partial_h: null or misaligned tensor");
+  return wgrad_partial_impl(g, (const float*)gy, (const float*)x, gw, workspace, workspace_bytes, VG_PREC_BF16, gy, x, stream, true);
+}
+
+static int wgrad_partial_impl(const vg_conv_geom* g, const float* gy, const float* x, float* gw, void* workspace,
+                              size_t workspace_bytes, int precision, const void* gy_planes, const void* x_planes,
+                              void* stream, bool io_h) {
   if (int e = vg_check_geom(g, "vg_conv2d_wgrad")) return e;
   if (precision < VG_PREC_F32 || precision > VG_PREC_F32_SPLIT)
     return vg_fail(VG_ERR_INVALID, "vg_conv2d_wgrad: unknown precision %d", precision);
@@ -156,7 +178,7 @@ extern "C" int vg_conv2d_wgrad_partial_prec(const vg_conv_geom* g, const float* 
                    need, workspace_bytes);
 
   // image stems (3 or 1 input channels) have a kernel of their own that fills the same slabs
-  if (pl.nsplit > 1) {
+  if (pl.nsplit > 1 && !io_h) {
     if (int r = vg_try_wgrad_stem(g, gy, x, (float*)workspace, pl.nsplit, (hipStream_t)stream)) return r < 0 ? r : VG_OK;
   }
 
@@ -173,11 +195,11 @@ extern "C" int vg_conv2d_wgrad_partial_prec(const vg_conv_geom* g, const float* 
   const int va = (g->Co % 4 == 0 && vg_aligned16(gy)) ? 4 : 1;
   const int vb = (g->Ci % 4 == 0 && vg_aligned16(x)) ? 4 : 1;
   dim3 grid((unsigned)(pl.mtiles * pl.ntiles), 1, (unsigned)pl.nsplit);
-  if (pgemm_serves(precision, 2, g) && pl.bn != 32) {
+  if (io_h || (pgemm_serves(precision, 2, g) && pl.bn != 32)) {
     const int np = vg_planes_of(precision);
     PgemmParams pp{};
     pp.g = p;
-    const size_t skip = slab_bytes(pl);
+    const size_t skip = io_h ? 0 : slab_bytes(pl);     // (both operands handed over: nothing is split into the workspace)
     if (workspace_bytes < skip) return vg_fail(VG_ERR_WORKSPACE, "vg_conv2d_wgrad: workspace too small for split mode");
     if (int e = pgemm_prepare(pp, gy, (long long)g->N * g->Ho * g->Wo * g->Co, x, (long long)g->N * g->H * g->W * g->Ci, np,
                               (char*)workspace + skip, workspace_bytes - skip, (hipStream_t)stream, "vg_conv2d_wgrad", gy_planes,

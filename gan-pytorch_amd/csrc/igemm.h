@@ -26,11 +26,9 @@
 #include <type_traits>
 #include "vg_internal.h"
 
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 enum { PREC_F32 = 0, PREC_BF16 = 1, PREC_SPLIT = 2 };   // PREC_SPLIT is served by pgemm.h; here it runs as f32
 

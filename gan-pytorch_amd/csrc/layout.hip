@@ -4,6 +4,8 @@
 
 #include <string.h>
 
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
 char* vg_error_buffer() {
   static thread_local char buf[512] = {0};
   return buf;
@@ -108,6 +110,75 @@ __global__ void __launch_bounds__(256) fill_kernel(float* __restrict__ out, floa
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) out[i] = v;
 }
 
+// ---- bf16 storage: conversions and the elementwise helpers on bf16 tensors; a lane handles 8 consecutive values ----
+__device__ __forceinline__ void widen8(const u32x4 t, float (&v)[8]) {
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    v[2 * j] = __builtin_bit_cast(float, t[j] << 16);
+    v[2 * j + 1] = __builtin_bit_cast(float, t[j] & 0xffff0000u);
+  }
+}
+__device__ __forceinline__ u32x4 narrow8(const float (&v)[8]) {   // round to nearest even
+  u32x4 t;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const f32x2 p = {v[2 * j], v[2 * j + 1]};
+    t[j] = __builtin_bit_cast(unsigned int, __builtin_convertvector(p, bf16x2));
+  }
+  return t;
+}
+
+__global__ void __launch_bounds__(256) narrow_kernel(const float* __restrict__ in, __bf16* __restrict__ out, size_t n, int vec) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x * 8;
+  for (size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 8; i < n; i += stride) {
+    if (vec && i + 8 <= n) {
+      const f32x4 a = *reinterpret_cast<const f32x4*>(in + i), b = *reinterpret_cast<const f32x4*>(in + i + 4);
+      const float v[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+      *reinterpret_cast<u32x4*>(out + i) = narrow8(v);
+    } else {
+      for (size_t j = i; j < n && j < i + 8; ++j) out[j] = (__bf16)in[j];
+    }
+  }
+}
+
+__global__ void __launch_bounds__(256) widen_kernel(const __bf16* __restrict__ in, float* __restrict__ out, size_t n, int vec) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x * 8;
+  for (size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 8; i < n; i += stride) {
+    if (vec && i + 8 <= n) {
+      float v[8];
+      widen8(*reinterpret_cast<const u32x4*>(in + i), v);
+      const f32x4 a = {v[0], v[1], v[2], v[3]}, b = {v[4], v[5], v[6], v[7]};
+      *reinterpret_cast<f32x4*>(out + i) = a;
+      *reinterpret_cast<f32x4*>(out + i + 4) = b;
+    } else {
+      for (size_t j = i; j < n && j < i + 8; ++j) out[j] = (float)in[j];
+    }
+  }
+}
+
+__global__ void __launch_bounds__(256) add_h_kernel(const __bf16* __restrict__ a, const __bf16* __restrict__ b,
+                                                    __bf16* __restrict__ out, size_t n, int vec) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x * 8;
+  for (size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 8; i < n; i += stride) {
+    if (vec && i + 8 <= n) {
+      float x[8], y[8];
+      widen8(*reinterpret_cast<const u32x4*>(a + i), x);
+      widen8(*reinterpret_cast<const u32x4*>(b + i), y);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) x[j] += y[j];
+      *reinterpret_cast<u32x4*>(out + i) = narrow8(x);
+    } else {
+      for (size_t j = i; j < n && j < i + 8; ++j) out[j] = (__bf16)((float)a[j] + (float)b[j]);
+    }
+  }
+}
+
+__global__ void __launch_bounds__(256) fill_h_kernel(__bf16* __restrict__ out, float v, size_t n) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  const __bf16 h = (__bf16)v;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) out[i] = h;
+}
+
 // out[0] = c0*a[0] + c1*b[0] + c2*c[0] (b, c nullable); aux[0] = a[0]/b[0] if aux: the scalar epilogue of the
 // adversary loss: 0.5*(fake+real) + lambda*penalty and the logged real/fake ratio, without leaving the device.
 __global__ void scalar_combine_kernel(const float* a, float c0, const float* b, float c1, const float* c, float c2, float* out,
@@ -154,6 +225,38 @@ extern "C" int vg_add(const float* a, const float* b, float* out, size_t n, void
   VG_REQUIRE(a && b && out && n > 0, "vg_add: bad arguments");
   hipLaunchKernelGGL(add_kernel, dim3(vg_stream_grid(n, 256)), dim3(256), 0, (hipStream_t)stream, a, b, out, n);
   VG_CHECK_LAUNCH("vg_add");
+  return VG_OK;
+}
+
+extern "C" int vg_add_h(const void* a, const void* b, void* out, size_t n, void* stream) {
+  VG_REQUIRE(a && b && out && n > 0, "vg_add_h: bad arguments");
+  const int vec = vg_aligned16(a) && vg_aligned16(b) && vg_aligned16(out) ? 1 : 0;
+  hipLaunchKernelGGL(add_h_kernel, dim3(vg_stream_grid((n + 7) / 8, 256)), dim3(256), 0, (hipStream_t)stream, (const __bf16*)a,
+                     (const __bf16*)b, (__bf16*)out, n, vec);
+  VG_CHECK_LAUNCH("vg_add_h");
+  return VG_OK;
+}
+
+extern "C" int vg_fill_h(void* out, float v, size_t n, void* stream) {
+  VG_REQUIRE(out && n > 0, "vg_fill_h: bad arguments");
+  hipLaunchKernelGGL(fill_h_kernel, dim3(vg_stream_grid(n, 256)), dim3(256), 0, (hipStream_t)stream, (__bf16*)out, v, n);
+  VG_CHECK_LAUNCH("vg_fill_h");
+  return VG_OK;
+}
+
+extern "C" int vg_cast_f32_to_bf16(const float* in, void* out, size_t n, void* stream) {
+  VG_REQUIRE(in && out && n > 0, "vg_cast_f32_to_bf16: bad arguments");
+  const int vec = vg_aligned16(in) && vg_aligned16(out) ? 1 : 0;
+  hipLaunchKernelGGL(narrow_kernel, dim3(vg_stream_grid((n + 7) / 8, 256)), dim3(256), 0, (hipStream_t)stream, in, (__bf16*)out, n, vec);
+  VG_CHECK_LAUNCH("vg_cast_f32_to_bf16");
+  return VG_OK;
+}
+
+extern "C" int vg_cast_bf16_to_f32(const void* in, float* out, size_t n, void* stream) {
+  VG_REQUIRE(in && out && n > 0, "vg_cast_bf16_to_f32: bad arguments");
+  const int vec = vg_aligned16(in) && vg_aligned16(out) ? 1 : 0;
+  hipLaunchKernelGGL(widen_kernel, dim3(vg_stream_grid((n + 7) / 8, 256)), dim3(256), 0, (hipStream_t)stream, (const __bf16*)in, out, n, vec);
+  VG_CHECK_LAUNCH("vg_cast_bf16_to_f32");
   return VG_OK;
 }
 

@@ -159,6 +159,32 @@ __device__ __forceinline__ void stv(float* p, const float (&v)[VEC]) {
   }
 }
 
+// bf16 storage: four values are one 8-byte access; widening is a shift, narrowing rounds to nearest even
+// (v_cvt_pk_bf16_f32).
+template <int VEC>
+__device__ __forceinline__ void ldv(const __bf16* p, float (&v)[VEC]) {
+  if constexpr (VEC == 4) {
+    const u32x2 t = *reinterpret_cast<const u32x2*>(p);
+    v[0] = __builtin_bit_cast(float, t[0] << 16);
+    v[1] = __builtin_bit_cast(float, t[0] & 0xffff0000u);
+    v[2] = __builtin_bit_cast(float, t[1] << 16);
+    v[3] = __builtin_bit_cast(float, t[1] & 0xffff0000u);
+  } else {
+    v[0] = (float)*p;
+  }
+}
+template <int VEC>
+__device__ __forceinline__ void stv(__bf16* p, const float (&v)[VEC]) {
+  if constexpr (VEC == 4) {
+    const f32x2 a = {v[0], v[1]}, b = {v[2], v[3]};
+    const u32x2 t = {__builtin_bit_cast(unsigned int, __builtin_convertvector(a, bf16x2)),
+                     __builtin_bit_cast(unsigned int, __builtin_convertvector(b, bf16x2))};
+    *reinterpret_cast<u32x2*>(p) = t;
+  } else {
+    *p = (__bf16)v[0];
+  }
+}
+
 // ---- elementwise -----------------------------------------------------------------------------------
 __device__ __forceinline__ float act_apply(float v, int act, float slope) {
   switch (act) {
@@ -183,8 +209,9 @@ __device__ __forceinline__ float act_grad(float ref, int act, float slope) {
 
 
 // ---- functors -------------------------------------------------------------------------------------
+template <class T>
 struct SumF {  // colsum
-  const float* x;
+  const T* x;
   template <int VEC>
   __device__ void eval(size_t off, int c, float (&acc)[1][VEC]) const {
     float a[VEC];
@@ -194,8 +221,9 @@ struct SumF {  // colsum
   }
 };
 
+template <class T>
 struct ShiftedMomentsF {  // sums of (x - x[0][c]) and its square
-  const float* x;
+  const T* x;
   template <int VEC>
   __device__ void eval(size_t off, int c, float (&acc)[2][VEC]) const {
     float a[VEC], s[VEC];
@@ -210,9 +238,13 @@ struct ShiftedMomentsF {  // sums of (x - x[0][c]) and its square
   }
 };
 
+template <class T>
 struct BnBwdF {  // sum g, sum g*xhat with g = gy * act'(.) when an activation is fused behind the norm: the mask comes
                  // from the activation's output (act_out) or, without it, from the recomputed pre-activation
-  const float *gy, *x, *mean, *invstd, *act_out, *gamma, *beta;
+  const T *gy, *x;
+  const float *mean, *invstd;
+  const T* act_out;
+  const float *gamma, *beta;
   int act;
   float slope;
   template <int VEC>
@@ -243,8 +275,12 @@ struct BnBwdF {  // sum g, sum g*xhat with g = gy * act'(.) when an activation i
   }
 };
 
+template <class T>
 struct BnDbwdF {  // sum g, sum g*xhat, sum u, sum u*xhat, sum u*g   (g as in BnBwdF)
-  const float *gy, *x, *u, *mean, *invstd, *act_out, *gamma, *beta;
+  const T *gy, *x, *u;
+  const float *mean, *invstd;
+  const T* act_out;
+  const float *gamma, *beta;
   int act;
   float slope;
   template <int VEC>
@@ -283,7 +319,8 @@ struct BnDbwdF {  // sum g, sum g*xhat, sum u, sum u*xhat, sum u*g   (g as in Bn
 // Epilogue of the moments reduction: batch mean / inverse std from the shifted sums, running-statistics update and the
 // batch counter, all in the kernel that finishes the reduction.
 struct BnFinalizeE {
-  const float* x;        // first row: the shift of the one-pass moments
+  const float* x;        // first row: the shift of the one-pass moments (f32 storage)
+  const __bf16* xh;      // the same for bf16 storage (exactly one of the two is set by vg_bn_stats)
   int M;
   float eps, momentum;
   float *mean, *invstd, *running_mean, *running_var;
@@ -292,7 +329,8 @@ struct BnFinalizeE {
   __device__ void operator()(int c, const double (&s)[NV]) const {
     const double n = (double)M;
     const double s1 = s[0] / n;
-    finish(c, (double)x[c] + s1, s[1] / n - s1 * s1);
+    const double shift = xh ? (double)(float)xh[c] : (double)x[c];
+    finish(c, shift + s1, s[1] / n - s1 * s1);
   }
   // mean and biased variance of column c (in double) -> the norm's statistics and running statistics
   __device__ void finish(int c, double mean_d, double var) const {
@@ -434,10 +472,10 @@ __global__ void __launch_bounds__(256) invstd_kernel(const float* var, float* in
   if (c < C) invstd[c] = 1.0f / sqrtf(var[c] + eps);
 }
 
-template <int VEC>
-__global__ void __launch_bounds__(256) bn_apply_kernel(const float* __restrict__ x, const float* __restrict__ mean,
+template <int VEC, class T>
+__global__ void __launch_bounds__(256) bn_apply_kernel(const T* __restrict__ x, const float* __restrict__ mean,
                                                        const float* __restrict__ invstd, const float* __restrict__ gamma,
-                                                       const float* __restrict__ beta, float* __restrict__ y, size_t nvec,
+                                                       const float* __restrict__ beta, T* __restrict__ y, size_t nvec,
                                                        int C, int act, float slope) {
   const int CG = C / VEC;
   const size_t stride = (size_t)gridDim.x * blockDim.x;
@@ -455,12 +493,12 @@ __global__ void __launch_bounds__(256) bn_apply_kernel(const float* __restrict__
   }
 }
 
-template <int VEC>
-__global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const float* __restrict__ gy, const float* __restrict__ x,
+template <int VEC, class T>
+__global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const T* __restrict__ gy, const T* __restrict__ x,
                                                            const float* __restrict__ mean, const float* __restrict__ invstd,
                                                            const float* __restrict__ gamma, const float* __restrict__ sums,
-                                                           float* __restrict__ gx, size_t nvec, int C, float inv_n,
-                                                           const float* __restrict__ act_out, int act, float slope,
+                                                           T* __restrict__ gx, size_t nvec, int C, float inv_n,
+                                                           const T* __restrict__ act_out, int act, float slope,
                                                            const float* __restrict__ beta) {
   const int CG = C / VEC;
   const size_t stride = (size_t)gridDim.x * blockDim.x;
@@ -495,9 +533,9 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const float* __restri
   }
 }
 
-template <int VEC>
-__global__ void __launch_bounds__(256) bn_bwd_eval_kernel(const float* __restrict__ gy, const float* __restrict__ invstd,
-                                                          const float* __restrict__ gamma, float* __restrict__ gx,
+template <int VEC, class T>
+__global__ void __launch_bounds__(256) bn_bwd_eval_kernel(const T* __restrict__ gy, const float* __restrict__ invstd,
+                                                          const float* __restrict__ gamma, T* __restrict__ gx,
                                                           size_t nvec, int C) {
   const int CG = C / VEC;
   const size_t stride = (size_t)gridDim.x * blockDim.x;
@@ -514,12 +552,12 @@ __global__ void __launch_bounds__(256) bn_bwd_eval_kernel(const float* __restric
 }
 
 // second derivative of the training-mode backward (see vegans_hip.h for the meaning of u, v, w)
-template <int VEC>
+template <int VEC, class T>
 __global__ void __launch_bounds__(256) bn_dbwd_apply_kernel(
-    const float* __restrict__ gy, const float* __restrict__ x, const float* __restrict__ u, const float* __restrict__ v,
+    const T* __restrict__ gy, const T* __restrict__ x, const T* __restrict__ u, const float* __restrict__ v,
     const float* __restrict__ w, const float* __restrict__ mean, const float* __restrict__ invstd,
-    const float* __restrict__ gamma, const float* __restrict__ sums5, float* __restrict__ d_gy, float* __restrict__ d_x,
-    size_t nvec, int C, float inv_n, const float* __restrict__ act_out, int act, float slope,
+    const float* __restrict__ gamma, const float* __restrict__ sums5, T* __restrict__ d_gy, T* __restrict__ d_x,
+    size_t nvec, int C, float inv_n, const T* __restrict__ act_out, int act, float slope,
     const float* __restrict__ beta) {
   const int CG = C / VEC;
   const size_t stride = (size_t)gridDim.x * blockDim.x;
@@ -587,8 +625,8 @@ __global__ void __launch_bounds__(256) bn_dbwd_gamma_kernel(const float* invstd,
   d_gamma[c] = invstd[c] * n * P;
 }
 
-template <int VEC>
-__global__ void __launch_bounds__(256) act_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, size_t nvec, int act,
+template <int VEC, class T>
+__global__ void __launch_bounds__(256) act_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, size_t nvec, int act,
                                                       float slope) {
   const size_t stride = (size_t)gridDim.x * blockDim.x;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += stride) {
@@ -600,9 +638,9 @@ __global__ void __launch_bounds__(256) act_fwd_kernel(const float* __restrict__ 
   }
 }
 
-template <int VEC>
-__global__ void __launch_bounds__(256) act_bwd_kernel(const float* __restrict__ gy, const float* __restrict__ ref,
-                                                      float* __restrict__ gx, size_t nvec, int act, float slope) {
+template <int VEC, class T>
+__global__ void __launch_bounds__(256) act_bwd_kernel(const T* __restrict__ gy, const T* __restrict__ ref,
+                                                      T* __restrict__ gx, size_t nvec, int act, float slope) {
   const size_t stride = (size_t)gridDim.x * blockDim.x;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += stride) {
     float g[VEC], a[VEC], o[VEC];
@@ -614,9 +652,9 @@ __global__ void __launch_bounds__(256) act_bwd_kernel(const float* __restrict__ 
   }
 }
 
-template <int VEC>
-__global__ void __launch_bounds__(256) act_dbwd_ref_kernel(const float* __restrict__ gg, const float* __restrict__ gy,
-                                                           const float* __restrict__ ref, float* __restrict__ d_ref,
+template <int VEC, class T>
+__global__ void __launch_bounds__(256) act_dbwd_ref_kernel(const T* __restrict__ gg, const T* __restrict__ gy,
+                                                           const T* __restrict__ ref, T* __restrict__ d_ref,
                                                            size_t nvec, int act) {
   const size_t stride = (size_t)gridDim.x * blockDim.x;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += stride) {
@@ -653,14 +691,14 @@ inline bool all_aligned(std::initializer_list<const void*> ps) {
 
 }  // namespace
 
-#define VG_LAUNCH_VEC(kernel, vec4, total, st, ...)                                                          \
+#define VG_LAUNCH_VEC(kernel, T_, vec4, total, st, ...)                                                      \
   do {                                                                                                       \
     if (vec4) {                                                                                              \
       const size_t nvec__ = (total) / 4;                                                                     \
-      hipLaunchKernelGGL((kernel<4>), dim3(vg_stream_grid(nvec__, 256)), dim3(256), 0, st, __VA_ARGS__);     \
+      hipLaunchKernelGGL((kernel<4, T_>), dim3(vg_stream_grid(nvec__, 256)), dim3(256), 0, st, __VA_ARGS__); \
     } else {                                                                                                 \
       const size_t nvec__ = (total);                                                                         \
-      hipLaunchKernelGGL((kernel<1>), dim3(vg_stream_grid(nvec__, 256)), dim3(256), 0, st, __VA_ARGS__);     \
+      hipLaunchKernelGGL((kernel<1, T_>), dim3(vg_stream_grid(nvec__, 256)), dim3(256), 0, st, __VA_ARGS__); \
     }                                                                                                        \
   } while (0)
 
@@ -674,19 +712,169 @@ extern "C" size_t vg_colsum_workspace_bytes(int M, int C) {
   return (size_t)row_blocks(M) * C * sizeof(double);
 }
 
+// Every entry point below exists twice: for f32 activations (the un-suffixed names) and, with the suffix _h, for
+// activations stored as bf16 (same arithmetic in f32 registers; per-channel vectors, sums and parameters stay f32).
+namespace {
+
+template <class T>
+int colsum_impl(const char* who, const T* x, float* out, int M, int C, void* ws, size_t ws_bytes, void* stream) {
+  VG_REQUIRE(x && out && M > 0 && C > 0, "%s: bad arguments", who);
+  SumF<T> f{x};
+  return run_colreduce<1>(who, f, M, C, all_aligned({x}), out, ws, ws_bytes, (hipStream_t)stream);
+}
+
+template <class T>
+int bn_stats_impl(const char* who, const T* x, int M, int C, float eps, float momentum, float* mean, float* invstd,
+                  float* running_mean, float* running_var, long long* num_batches_tracked, void* ws, size_t ws_bytes,
+                  void* stream) {
+  VG_REQUIRE(x && mean && invstd && M > 0 && C > 0, "%s: bad arguments", who);
+  ShiftedMomentsF<T> f{x};
+  BnFinalizeE fin{nullptr, nullptr, M, eps, momentum, mean, invstd, running_mean, running_var, num_batches_tracked};
+  if constexpr (std::is_same<T, float>::value) fin.x = x;
+  else fin.xh = x;
+  return run_colreduce_with<2>(who, f, M, C, all_aligned({x}), fin, ws, ws_bytes, (hipStream_t)stream);
+}
+
+template <class T>
+int bn_apply_impl(const char* who, const T* x, const float* mean, const float* invstd, const float* gamma,
+                  const float* beta, T* y, int M, int C, int act, float slope, void* stream) {
+  VG_REQUIRE(x && mean && invstd && y && M > 0 && C > 0, "%s: bad arguments", who);
+  const bool v4 = C % 4 == 0 && all_aligned({x, mean, invstd, gamma, beta, y});
+  const size_t total = (size_t)M * C;
+  VG_LAUNCH_VEC(bn_apply_kernel, T, v4, total, (hipStream_t)stream, x, mean, invstd, gamma, beta, y, nvec__, C, act, slope);
+  VG_CHECK_LAUNCH(who);
+  return VG_OK;
+}
+
+int check_mask_act(const void* act_out, int act, const char* who) {
+  if (act != VG_ACT_NONE && act != VG_ACT_RELU && act != VG_ACT_LRELU)
+    return vg_fail(VG_ERR_INVALID, "%s: only relu / leaky relu can be fused behind the norm", who);
+  if (act_out && act == VG_ACT_NONE)
+    return vg_fail(VG_ERR_INVALID, "%s: an activation output was passed without an activation code", who);
+  return 0;
+}
+
+template <class T>
+int bn_bwd_reduce_impl(const char* who, const T* gy, const T* x, const float* mean, const float* invstd, int M, int C,
+                       float* sums, void* ws, size_t ws_bytes, const T* act_out, int act, float slope,
+                       const float* gamma, const float* beta, void* stream) {
+  VG_REQUIRE(gy && x && mean && invstd && sums && M > 0 && C > 0, "%s: bad arguments", who);
+  if (int e = check_mask_act(act_out, act, who)) return e;
+  BnBwdF<T> f{gy, x, mean, invstd, act_out, gamma, beta, act, slope};
+  return run_colreduce<2>(who, f, M, C, all_aligned({gy, x, mean, invstd, act_out, gamma, beta}), sums, ws, ws_bytes,
+                          (hipStream_t)stream);
+}
+
+template <class T>
+int bn_bwd_apply_impl(const char* who, const T* gy, const T* x, const float* mean, const float* invstd,
+                      const float* gamma, const float* sums, T* gx, int M, int C, const T* act_out, int act, float slope,
+                      const float* beta, void* stream) {
+  VG_REQUIRE(gy && x && mean && invstd && sums && gx && M > 0 && C > 0, "%s: bad arguments", who);
+  if (int e = check_mask_act(act_out, act, who)) return e;
+  const bool v4 = C % 4 == 0 && all_aligned({gy, x, mean, invstd, gamma, sums, gx, act_out, beta});
+  const size_t total = (size_t)M * C;
+  const float inv_n = 1.0f / (float)M;
+  VG_LAUNCH_VEC(bn_bwd_apply_kernel, T, v4, total, (hipStream_t)stream, gy, x, mean, invstd, gamma, sums, gx, nvec__, C,
+                inv_n, act_out, act, slope, beta);
+  VG_CHECK_LAUNCH(who);
+  return VG_OK;
+}
+
+template <class T>
+int bn_bwd_eval_impl(const char* who, const T* gy, const float* invstd, const float* gamma, T* gx, int M, int C,
+                     void* stream) {
+  VG_REQUIRE(gy && invstd && gx && M > 0 && C > 0, "%s: bad arguments", who);
+  const bool v4 = C % 4 == 0 && all_aligned({gy, invstd, gamma, gx});
+  const size_t total = (size_t)M * C;
+  VG_LAUNCH_VEC(bn_bwd_eval_kernel, T, v4, total, (hipStream_t)stream, gy, invstd, gamma, gx, nvec__, C);
+  VG_CHECK_LAUNCH(who);
+  return VG_OK;
+}
+
+template <class T>
+int bn_dbwd_reduce_impl(const char* who, const T* gy, const T* x, const T* u, const float* mean, const float* invstd,
+                        int M, int C, float* sums5, void* ws, size_t ws_bytes, const T* act_out, int act, float slope,
+                        const float* gamma, const float* beta, void* stream) {
+  VG_REQUIRE(gy && x && u && mean && invstd && sums5 && M > 0 && C > 0, "%s: bad arguments", who);
+  if (int e = check_mask_act(act_out, act, who)) return e;
+  BnDbwdF<T> f{gy, x, u, mean, invstd, act_out, gamma, beta, act, slope};
+  return run_colreduce<5>(who, f, M, C, all_aligned({gy, x, u, mean, invstd, act_out, gamma, beta}), sums5, ws,
+                          ws_bytes, (hipStream_t)stream);
+}
+
+template <class T>
+int bn_dbwd_apply_impl(const char* who, const T* gy, const T* x, const T* u, const float* v, const float* w,
+                       const float* mean, const float* invstd, const float* gamma, const float* sums5, T* d_gy, T* d_x,
+                       float* d_gamma, int M, int C, const T* act_out, int act, float slope, const float* beta,
+                       void* stream) {
+  VG_REQUIRE(gy && x && u && mean && invstd && sums5 && d_gy && d_x && M > 0 && C > 0, "%s: bad arguments", who);
+  if (int e = check_mask_act(act_out, act, who)) return e;
+  const bool v4 = C % 4 == 0 && all_aligned({gy, x, u, v, w, mean, invstd, gamma, sums5, d_gy, d_x, act_out, beta});
+  const size_t total = (size_t)M * C;
+  const float inv_n = 1.0f / (float)M;
+  hipStream_t st = (hipStream_t)stream;
+  VG_LAUNCH_VEC(bn_dbwd_apply_kernel, T, v4, total, st, gy, x, u, v, w, mean, invstd, gamma, sums5, d_gy, d_x, nvec__, C,
+                inv_n, act_out, act, slope, beta);
+  VG_CHECK_LAUNCH(who);
+  if (d_gamma) {
+    hipLaunchKernelGGL(bn_dbwd_gamma_kernel, dim3((C + 255) / 256), dim3(256), 0, st, invstd, sums5, d_gamma, C, (float)M);
+    VG_CHECK_LAUNCH(who);
+  }
+  return VG_OK;
+}
+
+template <class T>
+int act_fwd_impl(const char* who, const T* x, T* y, size_t n, int act, float slope, void* stream) {
+  VG_REQUIRE(x && y && n > 0, "%s: bad arguments", who);
+  const bool v4 = n % 4 == 0 && all_aligned({x, y});
+  VG_LAUNCH_VEC(act_fwd_kernel, T, v4, n, (hipStream_t)stream, x, y, nvec__, act, slope);
+  VG_CHECK_LAUNCH(who);
+  return VG_OK;
+}
+
+template <class T>
+int act_bwd_impl(const char* who, const T* gy, const T* ref, T* gx, size_t n, int act, float slope, void* stream) {
+  VG_REQUIRE(gy && ref && gx && n > 0, "%s: bad arguments", who);
+  const bool v4 = n % 4 == 0 && all_aligned({gy, ref, gx});
+  VG_LAUNCH_VEC(act_bwd_kernel, T, v4, n, (hipStream_t)stream, gy, ref, gx, nvec__, act, slope);
+  VG_CHECK_LAUNCH(who);
+  return VG_OK;
+}
+
+template <class T>
+int act_dbwd_ref_impl(const char* who, const T* gg, const T* gy, const T* ref, T* d_ref, size_t n, int act,
+                      void* stream) {
+  VG_REQUIRE(gg && gy && ref && d_ref && n > 0, "%s: bad arguments", who);
+  VG_REQUIRE(act == VG_ACT_TANH || act == VG_ACT_SIGMOID, "%s: only tanh/sigmoid have a second derivative", who);
+  const bool v4 = n % 4 == 0 && all_aligned({gg, gy, ref, d_ref});
+  VG_LAUNCH_VEC(act_dbwd_ref_kernel, T, v4, n, (hipStream_t)stream, gg, gy, ref, d_ref, nvec__, act);
+  VG_CHECK_LAUNCH(who);
+  return VG_OK;
+}
+
+typedef const __bf16* HC;   // bf16 tensors cross the C ABI as void*
+typedef __bf16* HM;
+
+}  // namespace
+
 extern "C" int vg_colsum(const float* x, float* out, int M, int C, void* ws, size_t ws_bytes, void* stream) {
-  VG_REQUIRE(x && out && M > 0 && C > 0, "vg_colsum: bad arguments");
-  SumF f{x};
-  return run_colreduce<1>("vg_colsum", f, M, C, all_aligned({x}), out, ws, ws_bytes, (hipStream_t)stream);
+  return colsum_impl<float>("vg_colsum", x, out, M, C, ws, ws_bytes, stream);
+}
+extern "C" int vg_colsum_h(const void* x, float* out, int M, int C, void* ws, size_t ws_bytes, void* stream) {
+  return colsum_impl<__bf16>("vg_colsum_h", (HC)x, out, M, C, ws, ws_bytes, stream);
 }
 
 extern "C" int vg_bn_stats(const float* x, int M, int C, float eps, float momentum, float* mean, float* invstd,
                            float* running_mean, float* running_var, long long* num_batches_tracked, void* ws,
                            size_t ws_bytes, void* stream) {
-  VG_REQUIRE(x && mean && invstd && M > 0 && C > 0, "vg_bn_stats: bad arguments");
-  ShiftedMomentsF f{x};
-  BnFinalizeE fin{x, M, eps, momentum, mean, invstd, running_mean, running_var, num_batches_tracked};
-  return run_colreduce_with<2>("vg_bn_stats", f, M, C, all_aligned({x}), fin, ws, ws_bytes, (hipStream_t)stream);
+  return bn_stats_impl<float>("vg_bn_stats", x, M, C, eps, momentum, mean, invstd, running_mean, running_var,
+                              num_batches_tracked, ws, ws_bytes, stream);
+}
+extern "C" int vg_bn_stats_h(const void* x, int M, int C, float eps, float momentum, float* mean, float* invstd,
+                             float* running_mean, float* running_var, long long* num_batches_tracked, void* ws,
+                             size_t ws_bytes, void* stream) {
+  return bn_stats_impl<__bf16>("vg_bn_stats_h", (HC)x, M, C, eps, momentum, mean, invstd, running_mean, running_var,
+                               num_batches_tracked, ws, ws_bytes, stream);
 }
 
 void vg_bnstats_layout(int mode, const vg_conv_geom* g, int* tiles, long long* rows, int* cols);
@@ -699,7 +887,7 @@ extern "C" int vg_bn_stats_from_conv(int mode, const vg_conv_geom* g, const void
   long long rows;
   vg_bnstats_layout(mode, g, &tiles, &rows, &C);
   VG_REQUIRE(rows > 0 && rows < (1LL << 31), "vg_bn_stats_from_conv: bad geometry");
-  BnFinalizeE fin{nullptr, (int)rows, eps, momentum, mean, invstd, running_mean, running_var, num_batches_tracked};
+  BnFinalizeE fin{nullptr, nullptr, (int)rows, eps, momentum, mean, invstd, running_mean, running_var, num_batches_tracked};
   hipLaunchKernelGGL(bn_tiles_final_kernel, dim3((C + 3) / 4), dim3(1024), 0, (hipStream_t)stream, (const double*)stats, tiles,
                      C, (double)rows, fin);
   VG_CHECK_LAUNCH("vg_bn_stats_from_conv");
@@ -726,117 +914,109 @@ extern "C" int vg_bn_invstd_from_var(const float* var, float* invstd, int C, flo
 
 extern "C" int vg_bn_apply(const float* x, const float* mean, const float* invstd, const float* gamma, const float* beta,
                            float* y, int M, int C, int act, float slope, void* stream) {
-  VG_REQUIRE(x && mean && invstd && y && M > 0 && C > 0, "vg_bn_apply: bad arguments");
-  const bool v4 = C % 4 == 0 && all_aligned({x, mean, invstd, gamma, beta, y});
-  const size_t total = (size_t)M * C;
-  VG_LAUNCH_VEC(bn_apply_kernel, v4, total, (hipStream_t)stream, x, mean, invstd, gamma, beta, y, nvec__, C, act, slope);
-  VG_CHECK_LAUNCH("vg_bn_apply");
-  return VG_OK;
+  return bn_apply_impl<float>("vg_bn_apply", x, mean, invstd, gamma, beta, y, M, C, act, slope, stream);
 }
-
-static int check_mask_act(const float* act_out, int act, const char* who) {
-  if (act != VG_ACT_NONE && act != VG_ACT_RELU && act != VG_ACT_LRELU)
-    return vg_fail(VG_ERR_INVALID, "%s: only relu / leaky relu can be fused behind the norm", who);
-  if (act_out && act == VG_ACT_NONE)
-    return vg_fail(VG_ERR_INVALID, "%s: an activation output was passed without an activation code", who);
-  return 0;
+extern "C" int vg_bn_apply_h(const void* x, const float* mean, const float* invstd, const float* gamma, const float* beta,
+                             void* y, int M, int C, int act, float slope, void* stream) {
+  return bn_apply_impl<__bf16>("vg_bn_apply_h", (HC)x, mean, invstd, gamma, beta, (HM)y, M, C, act, slope, stream);
 }
 
 extern "C" int vg_bn_bwd_reduce(const float* gy, const float* x, const float* mean, const float* invstd, int M, int C,
                                 float* sums, void* ws, size_t ws_bytes, const float* act_out, int act, float slope,
                                 const float* gamma, const float* beta, void* stream) {
-  VG_REQUIRE(gy && x && mean && invstd && sums && M > 0 && C > 0, "vg_bn_bwd_reduce: bad arguments");
-  if (int e = check_mask_act(act_out, act, "vg_bn_bwd_reduce")) return e;
-  BnBwdF f{gy, x, mean, invstd, act_out, gamma, beta, act, slope};
-  return run_colreduce<2>("vg_bn_bwd_reduce", f, M, C, all_aligned({gy, x, mean, invstd, act_out, gamma, beta}), sums, ws,
-                          ws_bytes, (hipStream_t)stream);
+  return bn_bwd_reduce_impl<float>("vg_bn_bwd_reduce", gy, x, mean, invstd, M, C, sums, ws, ws_bytes, act_out, act, slope,
+                                   gamma, beta, stream);
+}
+extern "C" int vg_bn_bwd_reduce_h(const void* gy, const void* x, const float* mean, const float* invstd, int M, int C,
+                                  float* sums, void* ws, size_t ws_bytes, const void* act_out, int act, float slope,
+                                  const float* gamma, const float* beta, void* stream) {
+  return bn_bwd_reduce_impl<__bf16>("vg_bn_bwd_reduce_h", (HC)gy, (HC)x, mean, invstd, M, C, sums, ws, ws_bytes,
+                                    (HC)act_out, act, slope, gamma, beta, stream);
 }
 
 extern "C" int vg_bn_bwd_apply(const float* gy, const float* x, const float* mean, const float* invstd, const float* gamma,
                                const float* sums, float* gx, int M, int C, const float* act_out, int act, float slope,
                                const float* beta, void* stream) {
-  VG_REQUIRE(gy && x && mean && invstd && sums && gx && M > 0 && C > 0, "vg_bn_bwd_apply: bad arguments");
-  if (int e = check_mask_act(act_out, act, "vg_bn_bwd_apply")) return e;
-  const bool v4 = C % 4 == 0 && all_aligned({gy, x, mean, invstd, gamma, sums, gx, act_out, beta});
-  const size_t total = (size_t)M * C;
-  const float inv_n = 1.0f / (float)M;
-  VG_LAUNCH_VEC(bn_bwd_apply_kernel, v4, total, (hipStream_t)stream, gy, x, mean, invstd, gamma, sums, gx, nvec__, C, inv_n,
-                act_out, act, slope, beta);
-  VG_CHECK_LAUNCH("vg_bn_bwd_apply");
-  return VG_OK;
+  return bn_bwd_apply_impl<float>("vg_bn_bwd_apply", gy, x, mean, invstd, gamma, sums, gx, M, C, act_out, act, slope, beta,
+                                  stream);
+}
+extern "C" int vg_bn_bwd_apply_h(const void* gy, const void* x, const float* mean, const float* invstd, const float* gamma,
+                                 const float* sums, void* gx, int M, int C, const void* act_out, int act, float slope,
+                                 const float* beta, void* stream) {
+  return bn_bwd_apply_impl<__bf16>("vg_bn_bwd_apply_h", (HC)gy, (HC)x, mean, invstd, gamma, sums, (HM)gx, M, C,
+                                   (HC)act_out, act, slope, beta, stream);
 }
 
 extern "C" int vg_bn_bwd_eval(const float* gy, const float* invstd, const float* gamma, float* gx, int M, int C,
                               void* stream) {
-  VG_REQUIRE(gy && invstd && gx && M > 0 && C > 0, "vg_bn_bwd_eval: bad arguments");
-  const bool v4 = C % 4 == 0 && all_aligned({gy, invstd, gamma, gx});
-  const size_t total = (size_t)M * C;
-  VG_LAUNCH_VEC(bn_bwd_eval_kernel, v4, total, (hipStream_t)stream, gy, invstd, gamma, gx, nvec__, C);
-  VG_CHECK_LAUNCH("vg_bn_bwd_eval");
-  return VG_OK;
+  return bn_bwd_eval_impl<float>("vg_bn_bwd_eval", gy, invstd, gamma, gx, M, C, stream);
+}
+extern "C" int vg_bn_bwd_eval_h(const void* gy, const float* invstd, const float* gamma, void* gx, int M, int C,
+                                void* stream) {
+  return bn_bwd_eval_impl<__bf16>("vg_bn_bwd_eval_h", (HC)gy, invstd, gamma, (HM)gx, M, C, stream);
 }
 
 extern "C" int vg_bn_dbwd_reduce(const float* gy, const float* x, const float* u, const float* mean, const float* invstd,
                                  int M, int C, float* sums5, void* ws, size_t ws_bytes, const float* act_out, int act,
                                  float slope, const float* gamma, const float* beta, void* stream) {
-  VG_REQUIRE(gy && x && u && mean && invstd && sums5 && M > 0 && C > 0, "vg_bn_dbwd_reduce: bad arguments");
-  if (int e = check_mask_act(act_out, act, "vg_bn_dbwd_reduce")) return e;
-  BnDbwdF f{gy, x, u, mean, invstd, act_out, gamma, beta, act, slope};
-  return run_colreduce<5>("vg_bn_dbwd_reduce", f, M, C, all_aligned({gy, x, u, mean, invstd, act_out, gamma, beta}), sums5,
-                          ws, ws_bytes, (hipStream_t)stream);
+  return bn_dbwd_reduce_impl<float>("vg_bn_dbwd_reduce", gy, x, u, mean, invstd, M, C, sums5, ws, ws_bytes, act_out, act,
+                                    slope, gamma, beta, stream);
+}
+extern "C" int vg_bn_dbwd_reduce_h(const void* gy, const void* x, const void* u, const float* mean, const float* invstd,
+                                   int M, int C, float* sums5, void* ws, size_t ws_bytes, const void* act_out, int act,
+                                   float slope, const float* gamma, const float* beta, void* stream) {
+  return bn_dbwd_reduce_impl<__bf16>("vg_bn_dbwd_reduce_h", (HC)gy, (HC)x, (HC)u, mean, invstd, M, C, sums5, ws, ws_bytes,
+                                     (HC)act_out, act, slope, gamma, beta, stream);
 }
 
 extern "C" int vg_bn_dbwd_apply(const float* gy, const float* x, const float* u, const float* v, const float* w,
                                 const float* mean, const float* invstd, const float* gamma, const float* sums5, float* d_gy,
                                 float* d_x, float* d_gamma, int M, int C, const float* act_out, int act, float slope,
                                 const float* beta, void* stream) {
-  VG_REQUIRE(gy && x && u && mean && invstd && sums5 && d_gy && d_x && M > 0 && C > 0, "vg_bn_dbwd_apply: bad arguments");
-  if (int e = check_mask_act(act_out, act, "vg_bn_dbwd_apply")) return e;
-  const bool v4 = C % 4 == 0 && all_aligned({gy, x, u, v, w, mean, invstd, gamma, sums5, d_gy, d_x, act_out, beta});
-  const size_t total = (size_t)M * C;
-  const float inv_n = 1.0f / (float)M;
-  hipStream_t st = (hipStream_t)stream;
-  VG_LAUNCH_VEC(bn_dbwd_apply_kernel, v4, total, st, gy, x, u, v, w, mean, invstd, gamma, sums5, d_gy, d_x, nvec__, C, inv_n,
-                act_out, act, slope, beta);
-  VG_CHECK_LAUNCH("vg_bn_dbwd_apply");
-  if (d_gamma) {
-    hipLaunchKernelGGL(bn_dbwd_gamma_kernel, dim3((C + 255) / 256), dim3(256), 0, st, invstd, sums5, d_gamma, C, (float)M);
-    VG_CHECK_LAUNCH("vg_bn_dbwd_apply(gamma)");
-  }
-  return VG_OK;
+  return bn_dbwd_apply_impl<float>("vg_bn_dbwd_apply", gy, x, u, v, w, mean, invstd, gamma, sums5, d_gy, d_x, d_gamma, M, C,
+                                   act_out, act, slope, beta, stream);
+}
+extern "C" int vg_bn_dbwd_apply_h(const void* gy, const void* x, const void* u, const float* v, const float* w,
+                                  const float* mean, const float* invstd, const float* gamma, const float* sums5, void* d_gy,
+                                  void* d_x, float* d_gamma, int M, int C, const void* act_out, int act, float slope,
+                                  const float* beta, void* stream) {
+  return bn_dbwd_apply_impl<__bf16>("vg_bn_dbwd_apply_h", (HC)gy, (HC)x, (HC)u, v, w, mean, invstd, gamma, sums5, (HM)d_gy,
+                                    (HM)d_x, d_gamma, M, C, (HC)act_out, act, slope, beta, stream);
 }
 
 extern "C" int vg_act_fwd(const float* x, float* y, size_t n, int act, float slope, void* stream) {
-  VG_REQUIRE(x && y && n > 0, "vg_act_fwd: bad arguments");
-  const bool v4 = n % 4 == 0 && all_aligned({x, y});
-  VG_LAUNCH_VEC(act_fwd_kernel, v4, n, (hipStream_t)stream, x, y, nvec__, act, slope);
-  VG_CHECK_LAUNCH("vg_act_fwd");
-  return VG_OK;
+  return act_fwd_impl<float>("vg_act_fwd", x, y, n, act, slope, stream);
+}
+extern "C" int vg_act_fwd_h(const void* x, void* y, size_t n, int act, float slope, void* stream) {
+  return act_fwd_impl<__bf16>("vg_act_fwd_h", (HC)x, (HM)y, n, act, slope, stream);
 }
 
 extern "C" int vg_act_bwd(const float* gy, const float* ref, float* gx, size_t n, int act, float slope, void* stream) {
-  VG_REQUIRE(gy && ref && gx && n > 0, "vg_act_bwd: bad arguments");
-  const bool v4 = n % 4 == 0 && all_aligned({gy, ref, gx});
-  VG_LAUNCH_VEC(act_bwd_kernel, v4, n, (hipStream_t)stream, gy, ref, gx, nvec__, act, slope);
-  VG_CHECK_LAUNCH("vg_act_bwd");
-  return VG_OK;
+  return act_bwd_impl<float>("vg_act_bwd", gy, ref, gx, n, act, slope, stream);
+}
+extern "C" int vg_act_bwd_h(const void* gy, const void* ref, void* gx, size_t n, int act, float slope, void* stream) {
+  return act_bwd_impl<__bf16>("vg_act_bwd_h", (HC)gy, (HC)ref, (HM)gx, n, act, slope, stream);
 }
 
 extern "C" int vg_act_dbwd_ref(const float* gg, const float* gy, const float* ref, float* d_ref, size_t n, int act,
                                void* stream) {
-  VG_REQUIRE(gg && gy && ref && d_ref && n > 0, "vg_act_dbwd_ref: bad arguments");
-  VG_REQUIRE(act == VG_ACT_TANH || act == VG_ACT_SIGMOID, "vg_act_dbwd_ref: only tanh/sigmoid have a second derivative");
-  const bool v4 = n % 4 == 0 && all_aligned({gg, gy, ref, d_ref});
-  VG_LAUNCH_VEC(act_dbwd_ref_kernel, v4, n, (hipStream_t)stream, gg, gy, ref, d_ref, nvec__, act);
-  VG_CHECK_LAUNCH("vg_act_dbwd_ref");
-  return VG_OK;
+  return act_dbwd_ref_impl<float>("vg_act_dbwd_ref", gg, gy, ref, d_ref, n, act, stream);
+}
+extern "C" int vg_act_dbwd_ref_h(const void* gg, const void* gy, const void* ref, void* d_ref, size_t n, int act,
+                                 void* stream) {
+  return act_dbwd_ref_impl<__bf16>("vg_act_dbwd_ref_h", (HC)gg, (HC)gy, (HC)ref, (HM)d_ref, n, act, stream);
 }
 
 extern "C" int vg_bcast_rows(const float* v, float* out, int M, int C, void* stream) {
   VG_REQUIRE(v && out && M > 0 && C > 0, "vg_bcast_rows: bad arguments");
   const bool v4 = C % 4 == 0 && all_aligned({v, out});
   const size_t total = (size_t)M * C;
-  VG_LAUNCH_VEC(bcast_rows_kernel, v4, total, (hipStream_t)stream, v, out, nvec__, C);
+  if (v4) {
+    const size_t nvec = total / 4;
+    hipLaunchKernelGGL((bcast_rows_kernel<4>), dim3(vg_stream_grid(nvec, 256)), dim3(256), 0, (hipStream_t)stream, v, out, nvec, C);
+  } else {
+    hipLaunchKernelGGL((bcast_rows_kernel<1>), dim3(vg_stream_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, v, out, total, C);
+  }
   VG_CHECK_LAUNCH("vg_bcast_rows");
   return VG_OK;
 }

@@ -32,7 +32,10 @@ static __device__ __attribute__((aligned(16))) unsigned int vg_zero_page_u[4] = 
 
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 
-template <int MODE, int BM, int BN, int WAVES_M, int NP, int NW, int BK_ = 32>
+// OUT_H: the result leaves as bf16 (round to nearest even) instead of f32 - the convolution of a network whose
+// activations are stored as bf16. Two neighbouring lanes (columns c, c + 1) exchange one accumulator per pair of rows,
+// so that every lane stores a packed pair of columns: 4-byte stores, 16 lanes per 64-byte row segment.
+template <int MODE, int BM, int BN, int WAVES_M, int NP, int NW, int BK_ = 32, bool OUT_H = false>
 __global__ void __launch_bounds__(NW * 64) pgemm_kernel(const PgemmParams pp) {
   const IgemmParams& p = pp.g;
   constexpr int NT = NW * 64;
@@ -460,6 +463,47 @@ __global__ void __launch_bounds__(NW * 64) pgemm_kernel(const PgemmParams pp) {
       for (int ni = 0; ni < TN; ++ni) asm volatile("" ::"v"(bcol[ni]));
     }
   }
+  if constexpr (OUT_H) {
+    static_assert(MODE != MODE_WGRAD, "weight gradients leave as f32 slabs");
+    __bf16* outh = reinterpret_cast<__bf16*>(p.out) + n0 + wn * TN * 32 + (r & ~1);
+    const bool odd = (lane & 1) != 0;
+#pragma unroll
+    for (int mi = 0; mi < TM; ++mi) {
+      const int row_t = m0 + (wm * TM + mi) * 32 + 4 * h;
+#pragma unroll
+      for (int e2 = 0; e2 < 8; ++e2) {
+        // rows of accumulators 2 e2 and 2 e2 + 1 are neighbours; the even lane stores the first, the odd lane the second
+        const int dr = ((2 * e2) & 3) + 8 * ((2 * e2) >> 2) + (odd ? 1 : 0);
+        const int row = row_t + dr;
+        const bool rok = row < M;
+        size_t roff;
+        if constexpr (MODE == MODE_DGRAD) {
+          const int rc = rok ? row : 0;
+          const int n = vg_div_row(rc, plane, inv_plane, fast), rem = rc - n * plane;
+          const int ii = vg_div_row(rem, roww, inv_roww, fast), jj = rem - ii * roww;
+          roff = (size_t)((n * p.H + ii * p.sh + off_h) * p.W + jj * p.sw + off_w) * p.Ncols;
+        } else {
+          roff = (size_t)row * p.Ncols;
+        }
+#pragma unroll
+        for (int ni = 0; ni < TN; ++ni) {
+          float v0 = acc[mi][ni][2 * e2], v1 = acc[mi][ni][2 * e2 + 1];
+          if (has_bias) {
+            v0 += bcol[ni];
+            v1 += bcol[ni];
+          }
+          const float keep = odd ? v1 : v0, send = odd ? v0 : v1;
+          const float recv = __builtin_bit_cast(
+              float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, send), 0xB1, 0xF, 0xF, false));   // lane ^ 1
+          const f32x2 pr = {odd ? recv : keep, odd ? keep : recv};
+          if (rok && cok[ni])
+            *reinterpret_cast<unsigned int*>(outh + roff + ni * 32) =
+                __builtin_bit_cast(unsigned int, __builtin_convertvector(pr, bf16x2));
+        }
+      }
+    }
+    return;
+  }
   float* colp = outp + n0 + wn * TN * 32 + r;
 #pragma unroll
   for (int mi = 0; mi < TM; ++mi) {
@@ -492,13 +536,13 @@ __global__ void __launch_bounds__(NW * 64) pgemm_kernel(const PgemmParams pp) {
 }
 
 // Tiles served: 128x128, 128x64, 64x128 (eight waves) and 64x64 (four waves).
-template <int MODE, int NP>
+template <int MODE, int NP, bool OUT_H = false>
 static inline int pgemm_launch(const PgemmParams& pp, int bm, int bn, dim3 grid, hipStream_t st) {
   constexpr int BK = NP == 1 ? 64 : 32;     // a single plane leaves room for 64-deep tiles: half the barriers per flop
-  if (bm == 128 && bn == 128) vg_launch_timed(pgemm_kernel<MODE, 128, 128, 2, NP, 8, BK>, grid, dim3(512), 0, st, pp);
-  else if (bm == 128 && bn == 64) vg_launch_timed(pgemm_kernel<MODE, 128, 64, 4, NP, 8, BK>, grid, dim3(512), 0, st, pp);
-  else if (bm == 64 && bn == 128) vg_launch_timed(pgemm_kernel<MODE, 64, 128, 2, NP, 8, BK>, grid, dim3(512), 0, st, pp);
-  else if (bm == 64 && bn == 64) vg_launch_timed(pgemm_kernel<MODE, 64, 64, 2, NP, 4, BK>, grid, dim3(256), 0, st, pp);
+  if (bm == 128 && bn == 128) vg_launch_timed(pgemm_kernel<MODE, 128, 128, 2, NP, 8, BK, OUT_H>, grid, dim3(512), 0, st, pp);
+  else if (bm == 128 && bn == 64) vg_launch_timed(pgemm_kernel<MODE, 128, 64, 4, NP, 8, BK, OUT_H>, grid, dim3(512), 0, st, pp);
+  else if (bm == 64 && bn == 128) vg_launch_timed(pgemm_kernel<MODE, 64, 128, 2, NP, 8, BK, OUT_H>, grid, dim3(512), 0, st, pp);
+  else if (bm == 64 && bn == 64) vg_launch_timed(pgemm_kernel<MODE, 64, 64, 2, NP, 4, BK, OUT_H>, grid, dim3(256), 0, st, pp);
   else return -1;
   return 0;
 }

@@ -6,8 +6,12 @@
 #include <stdio.h>
 #include "../../include/vegans_hip.h"
 
+#include <type_traits>
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
 // Thread-local error text returned by vg_last_error().
 char* vg_error_buffer();

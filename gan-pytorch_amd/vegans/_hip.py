@@ -122,6 +122,27 @@ SIGNATURES = {
     "vg_grad_sum_multi": (c_int, [c_int, _P, _P, _P, _P, _P, _P]),
     "vg_sgd_step": (c_int, [_P, _P, _P, c_size_t, POINTER(SgdCfg), _P]),
     "vg_clamp": (c_int, [_P, c_size_t, c_float, c_float, _P]),
+    # activations stored as bf16
+    "vg_conv2d_h_applies": (c_int, [c_int, _G]),
+    "vg_conv2d_fwd_h": (c_int, [_G, _P, _P, _P, _P, _P]),
+    "vg_conv2d_dgrad_h": (c_int, [_G, _P, _P, _P, _P, _P]),
+    "vg_conv2d_wgrad_partial_h": (c_int, [_G, _P, _P, _P, _P, c_size_t, _P]),
+    "vg_cast_f32_to_bf16": (c_int, [_P, _P, c_size_t, _P]),
+    "vg_cast_bf16_to_f32": (c_int, [_P, _P, c_size_t, _P]),
+    "vg_add_h": (c_int, [_P, _P, _P, c_size_t, _P]),
+    "vg_fill_h": (c_int, [_P, c_float, c_size_t, _P]),
+    "vg_colsum_h": (c_int, [_P, _P, c_int, c_int, _P, c_size_t, _P]),
+    "vg_bn_stats_h": (c_int, [_P, c_int, c_int, c_float, c_float, _P, _P, _P, _P, _P, _P, c_size_t, _P]),
+    "vg_bn_apply_h": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_float, _P]),
+    "vg_bn_bwd_reduce_h": (c_int, [_P, _P, _P, _P, c_int, c_int, _P, _P, c_size_t, _P, c_int, c_float, _P, _P, _P]),
+    "vg_bn_bwd_apply_h": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, c_int, _P, c_int, c_float, _P, _P]),
+    "vg_bn_bwd_eval_h": (c_int, [_P, _P, _P, _P, c_int, c_int, _P]),
+    "vg_bn_dbwd_reduce_h": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, _P, _P, c_size_t, _P, c_int, c_float, _P, _P, _P]),
+    "vg_bn_dbwd_apply_h": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, _P, c_int, c_float,
+                                   _P, _P]),
+    "vg_act_fwd_h": (c_int, [_P, _P, c_size_t, c_int, c_float, _P]),
+    "vg_act_bwd_h": (c_int, [_P, _P, _P, c_size_t, c_int, c_float, _P]),
+    "vg_act_dbwd_ref_h": (c_int, [_P, _P, _P, _P, c_size_t, c_int, _P]),
 }
 
 _lib = None
@@ -167,6 +188,24 @@ def _ptr(t):
     if t.dtype != torch.float32:
         raise HipError("tensor dtype %s: the kernels compute in float32" % t.dtype)
     return c_void_p(t.data_ptr())
+
+
+def _hptr(t):
+    """Device pointer of a dense bfloat16 GPU tensor (None -> null): the activations of the bf16 storage mode."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise HipError("tensor is not on the GPU: this engine only runs on MI355X (device='cuda')")
+    if t.dtype != torch.bfloat16:
+        raise HipError("tensor dtype %s where a bfloat16 activation is expected" % t.dtype)
+    return c_void_p(t.data_ptr())
+
+
+def _aptr(t, like):
+    """Pointer of activation `t`, which must have the storage type of `like` (kernels take one type per call)."""
+    if t is None:
+        return None
+    return _hptr(t) if like.dtype == torch.bfloat16 else _ptr(t)
 
 
 def _dense(t):

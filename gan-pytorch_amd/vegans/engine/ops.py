@@ -32,6 +32,52 @@ from .._hip import ConvGeom, _ptr, _stream, call, workspace
 from . import grads, streams
 
 CL = torch.channels_last
+F32 = torch.float32
+BF16 = torch.bfloat16
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# storage types: activations are f32, or - in the bf16 mode - bf16 wherever the channel count is a multiple of 8
+# ----------------------------------------------------------------------------------------------------------------
+def _p(t):
+    """Device pointer of an activation of either storage type (None -> null). The kernel entry point is chosen with
+    `_A` from the same tensor, and `_same_storage` has checked that all activations of the call share the type."""
+    if t is None:
+        return None
+    if not t.is_cuda or t.dtype not in (F32, BF16):
+        raise _hip.HipError("activation on %s with dtype %s: expected float32 or bfloat16 on the GPU" % (t.device, t.dtype))
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def _A(name, like):
+    """Entry point `name` for activations stored like `like`: the `_h` twin for bf16."""
+    return name + "_h" if like.dtype == BF16 else name
+
+
+def _same_storage(*ts):
+    kinds = {t.dtype for t in ts if t is not None}
+    if len(kinds) > 1:
+        raise _hip.HipError("activations of one kernel call differ in storage type: %s" % sorted(str(k) for k in kinds))
+
+
+def _cast_raw(t, dtype):
+    """`t` converted to `dtype` (f32 <-> bf16, round to nearest even) with its memory order kept; no autograd."""
+    if t is None or t.dtype == dtype:
+        return t
+    if not _hip._dense(t):
+        t = _plain_contiguous(t)
+    out = torch.empty_like(t, dtype=dtype)
+    if out.stride() != t.stride():
+        raise _hip.HipError("cannot convert a tensor with strides %s in place order" % (tuple(t.stride()),))
+    if dtype == BF16:
+        call("vg_cast_f32_to_bf16", _ptr(t), _p(out), c_size_t(t.numel()), _stream())
+    else:
+        call("vg_cast_bf16_to_f32", _p(t), _ptr(out), c_size_t(t.numel()), _stream())
+    return out
+
+
+def _f32(t):
+    return _cast_raw(t, F32)
 
 
 # ----------------------------------------------------------------------------------------------------------------
@@ -40,8 +86,8 @@ CL = torch.channels_last
 def _require_gpu(t):
     if not t.is_cuda:
         raise _hip.HipError("input tensor is on %s: the engine only runs on the GPU" % t.device)
-    if t.dtype != torch.float32:
-        raise _hip.HipError("input tensor is %s: the engine computes in float32" % t.dtype)
+    if t.dtype != F32 and t.dtype != BF16:
+        raise _hip.HipError("input tensor is %s: the engine computes in float32 (activations may be stored as bfloat16)" % t.dtype)
 
 
 def to_nhwc(t):
@@ -55,6 +101,8 @@ def to_nhwc(t):
         t = _plain_contiguous(t)
         if t.is_contiguous(memory_format=CL):
             return t
+    if t.dtype == BF16:       # rare (a bf16 feature vector viewed as an image by the user's module): through f32
+        return _cast_raw(to_nhwc(_f32(t)), BF16)
     n, c, h, w = t.shape
     out = torch.empty((n, c, h, w), dtype=t.dtype, device=t.device, memory_format=CL)
     call("vg_nchw_to_nhwc", _ptr(t), _ptr(out), n, c, h * w, _stream())
@@ -68,6 +116,8 @@ def to_nchw(t):
         return t if t.is_contiguous() else _plain_contiguous(t)
     if not t.is_contiguous(memory_format=CL):
         return to_nchw(_plain_contiguous(t))
+    if t.dtype == BF16:
+        return _cast_raw(to_nchw(_f32(t)), BF16)
     n, c, h, w = t.shape
     out = torch.empty((n, c, h, w), dtype=t.dtype, device=t.device)
     call("vg_nhwc_to_nchw", _ptr(t), _ptr(out), n, c, h * w, _stream())
@@ -80,25 +130,31 @@ def _plain_contiguous(t):
     # (expands, spatial slices) do not occur on the training path; refuse instead of silently running a stock copy
     # kernel.
     shape, stride = tuple(t.shape), tuple(t.stride())
+    # a bf16 slice moves as 4-byte words (pairs of channels): the copy kernel only moves bits
+    half = 2 if t.dtype == BF16 else 1
     if t.dim() == 4:
         n, c, h, w = shape
         ctot = stride[3]
         if stride[1] == 1 and ctot > c and stride[2] == w * ctot and stride[0] == h * w * ctot:
+            if half == 2 and (c % 2 or ctot % 2 or t.data_ptr() % 4):
+                raise _hip.HipError("bf16 channel slice of %d of %d channels is not made of whole 4-byte words" % (c, ctot))
             out = torch.empty(shape, dtype=t.dtype, device=t.device, memory_format=CL)
-            call("vg_slice_channels", _ptr(t), ctot, 0, c, _ptr(out), c_size_t(n * h * w), _stream())
+            call("vg_slice_channels", _p(t), ctot // half, 0, c // half, _p(out), c_size_t(n * h * w), _stream())
             return out
     if t.dim() == 2 and stride[1] == 1 and stride[0] > shape[1]:
+        if half == 2 and (shape[1] % 2 or stride[0] % 2 or t.data_ptr() % 4):
+            raise _hip.HipError("bf16 column slice is not made of whole 4-byte words")
         out = torch.empty(shape, dtype=t.dtype, device=t.device)
-        call("vg_slice_channels", _ptr(t), stride[0], 0, shape[1], _ptr(out), c_size_t(shape[0]), _stream())
+        call("vg_slice_channels", _p(t), stride[0] // half, 0, shape[1] // half, _p(out), c_size_t(shape[0]), _stream())
         return out
     raise _hip.HipError("tensor with strides %s (shape %s) is neither NCHW- nor NHWC-contiguous" %
                         (tuple(t.stride()), tuple(t.shape)))
 
 
-def _new_act(n, c, h, w, like, flat):
+def _new_act(n, c, h, w, like, flat, dtype=F32):
     if flat:
-        return torch.empty((n, c), dtype=torch.float32, device=like.device)
-    return torch.empty((n, c, h, w), dtype=torch.float32, device=like.device, memory_format=CL)
+        return torch.empty((n, c), dtype=dtype, device=like.device)
+    return torch.empty((n, c, h, w), dtype=dtype, device=like.device, memory_format=CL)
 
 
 def _weight_mem(w):
@@ -226,27 +282,70 @@ class inputs_only:
         inputs_only.active = self.prev
 
 
-PRECISIONS = {"fp32": 0, "f32": 0, "float32": 0, "bf16": 1, "bfloat16": 1, "fp32_split": 2, "bf16x3": 2}
-_PRECISION_NAMES = {0: "fp32", 1: "bf16", 2: "fp32_split"}
-_precision = PRECISIONS[os.environ.get("VEGANS_HIP_PRECISION", "fp32").lower()]
+PRECISIONS = {"fp32": 0, "f32": 0, "float32": 0, "bf16": 1, "bfloat16": 1, "bf16_compute": 1, "fp32_split": 2,
+              "bf16x3": 2}
+_CANONICAL = {"f32": "fp32", "float32": "fp32", "bfloat16": "bf16", "bf16x3": "fp32_split"}
+_mode = os.environ.get("VEGANS_HIP_PRECISION", "fp32").lower()
+_mode = _CANONICAL.get(_mode, _mode)
+_precision = PRECISIONS[_mode]
 
 
 def set_matmul_precision(name):
-    """Multiplier precision of the convolution / linear contractions: "fp32" (default; f32 MFMA products),
-    "fp32_split" (f32-grade products computed on the bf16 matrix cores: operands split exactly into three bf16 terms,
-    six cross products accumulated in f32; agrees with "fp32" to f32 rounding noise) or "bf16" (operands rounded to
-    bf16 inside the matrix cores, f32 accumulation). Activations, weights, optimizer state and every other kernel stay
-    f32 in all three. Returns the previous name."""
-    global _precision
+    """Precision mode of the engine. "fp32" (default; f32 MFMA products, f32 tensors), "fp32_split" (f32-grade products
+    computed on the bf16 matrix cores: operands split exactly into three bf16 terms, six cross products accumulated in
+    f32; agrees with "fp32" to f32 rounding noise), "bf16" (a bf16 DATA PATH: feature maps and their gradients - every
+    activation whose channel count is a multiple of 8 - are stored as bf16 and feed the bf16 matrix cores as they lie in
+    memory; parameters, their gradients, optimizer state, batch statistics, losses, images and scores stay f32, and all
+    arithmetic between a load and a store is f32) or "bf16_compute" (f32 tensors throughout; only the operands of the
+    contractions are rounded to bf16 on their way into the matrix cores). Returns the previous name."""
+    global _precision, _mode
     if name not in PRECISIONS:
         raise ValueError("precision must be one of %s" % sorted(PRECISIONS))
-    previous = _PRECISION_NAMES[_precision]
+    previous = _mode
+    _mode = _CANONICAL.get(name, name)
     _precision = PRECISIONS[name]
     return previous
 
 
 def matmul_precision():
-    return _PRECISION_NAMES[_precision]
+    return _mode
+
+
+def storage_h():
+    """Whether feature maps are stored as bf16 (the "bf16" mode)."""
+    return _mode == "bf16"
+
+
+def _feature_dtype(channels):
+    """Storage type of an activation the engine produces with `channels` channels / features: bf16 for feature maps
+    in the bf16 mode; images, scores and other narrow tensors (channel counts that are not multiples of 8) stay f32."""
+    return BF16 if (_mode == "bf16" and channels % 8 == 0) else F32
+
+
+class CastFn(Function):
+    """Storage-type conversion inside a differentiable graph (its backward converts back): used where a gradient has
+    to be returned in the storage type of the tensor it belongs to."""
+
+    @staticmethod
+    def forward(ctx, t, dtype):
+        ctx.src = t.dtype
+        return _cast_raw(t, dtype)
+
+    @staticmethod
+    def backward(ctx, g):
+        return (g if g.dtype == ctx.src else CastFn.apply(g, ctx.src)), None
+
+
+def _stored_like(g, ref):
+    """Gradient `g` in the storage type of `ref`, the tensor it is the gradient of."""
+    if g is None or g.dtype == ref.dtype:
+        return g
+    return CastFn.apply(g, ref.dtype)
+
+
+def as_f32(t):
+    """`t` as an f32 tensor (differentiable): what leaves a network for the losses, the penalty and the caller."""
+    return CastFn.apply(t, F32) if t.dtype == BF16 else t
 
 
 def _launch_conv(mode, g, fn):
@@ -305,6 +404,20 @@ class _PlaneCache:
              _stream())
         self.entries[key] = (t, t._version, planes)
         return ctypes.c_void_p(planes.data_ptr())
+
+    def bf16_copy(self, t):
+        """bf16 copy of f32 tensor `t` in its memory order (a weight on its way into the bf16 contractions); kept for
+        the rest of the iteration like the planes above."""
+        key = (t.data_ptr(), "h")
+        if self.active:
+            hit = self.entries.get(key)
+            if hit is not None and hit[0]._version == hit[1] and hit[0].numel() == t.numel():
+                return hit[2]
+        copy = torch.empty(t.numel(), dtype=BF16, device=t.device)
+        call("vg_cast_f32_to_bf16", _ptr(t), _p(copy), c_size_t(t.numel()), _stream())
+        if self.active:
+            self.entries[key] = (t, t._version, copy)
+        return copy
 
 
 plane_cache = _PlaneCache()
@@ -485,12 +598,35 @@ def _conv_with_stats(mode, g, args, out, src=None):
     return True
 
 
-def raw_conv_fwd(g, x, w, bias):
+def _h_contraction(mode, g, a, b, out_dtype):
+    """Whether contraction `mode` runs on bf16 tensors: bf16 storage mode, a result stored as bf16 (weight gradients are
+    f32 always) and a geometry the bf16 kernels serve. Operands that arrive as f32 are converted first."""
+    if _mode != "bf16" or (mode != 2 and out_dtype != BF16):
+        return False
+    return bool(_hip.load().vg_conv2d_h_applies(mode, ctypes.byref(g.c)))
+
+
+def raw_conv_fwd(g, x, w, bias, out_dtype=None):
     x, w = to_nhwc(x), _weight_mem(w)
     _check_shape(x, g.x_shape(), "conv input")
     if w.numel() != g.w_numel():
         raise _hip.HipError("weight has %d elements, geometry expects %d" % (w.numel(), g.w_numel()))
+    if out_dtype is None:
+        out_dtype = _feature_dtype(g.Co)
+    if _h_contraction(0, g, x, w, out_dtype):
+        xh = _cast_raw(x, BF16)
+        wh = plane_cache.bf16_copy(w) if w.dtype == F32 else w
+        y = _new_act(g.N, g.Co, g.Ho, g.Wo, x, g.flat, BF16)
+        _launch_conv(0, g, lambda: call("vg_conv2d_fwd_h", ctypes.byref(g.c), _p(xh), _p(wh), _ptr(bias), _p(y), _stream()))
+        return y
+    x, w = _f32(x), _f32(w)
     y = _new_act(g.N, g.Co, g.Ho, g.Wo, x, g.flat)
+    if out_dtype != F32:      # a shape the bf16 kernels do not serve: f32 kernel, result converted
+        return _cast_raw(_raw_conv_fwd_f32(g, x, w, bias, y), out_dtype)
+    return _raw_conv_fwd_f32(g, x, w, bias, y)
+
+
+def _raw_conv_fwd_f32(g, x, w, bias, y):
     src = norm_bwd.take_request()
     if norm_stats.take_request():
         src = None
@@ -505,12 +641,27 @@ def raw_conv_fwd(g, x, w, bias):
     return y
 
 
-def raw_conv_dgrad(g, gy, w, bias):
+def raw_conv_dgrad(g, gy, w, bias, out_dtype=None):
     gy, w = to_nhwc(gy), _weight_mem(w)
     _check_shape(gy, g.y_shape(), "conv output-side tensor")
     if w.numel() != g.w_numel():
         raise _hip.HipError("weight has %d elements, geometry expects %d" % (w.numel(), g.w_numel()))
+    if out_dtype is None:
+        out_dtype = _feature_dtype(g.Ci)
+    if _h_contraction(1, g, gy, w, out_dtype):
+        gh = _cast_raw(gy, BF16)
+        wh = plane_cache.bf16_copy(w) if w.dtype == F32 else w
+        gx = _new_act(g.N, g.Ci, g.H, g.W, gy, g.flat, BF16)
+        _launch_conv(1, g, lambda: call("vg_conv2d_dgrad_h", ctypes.byref(g.c), _p(gh), _p(wh), _ptr(bias), _p(gx), _stream()))
+        return gx
+    gy, w = _f32(gy), _f32(w)
     gx = _new_act(g.N, g.Ci, g.H, g.W, gy, g.flat)
+    if out_dtype != F32:
+        return _cast_raw(_raw_conv_dgrad_f32(g, gy, w, bias, gx), out_dtype)
+    return _raw_conv_dgrad_f32(g, gy, w, bias, gx)
+
+
+def _raw_conv_dgrad_f32(g, gy, w, bias, gx):
     src = norm_bwd.take_request()
     if norm_stats.take_request():
         src = None
@@ -535,6 +686,16 @@ def raw_conv_wgrad(g, gy, x, w_shape):
         gw = torch.empty(w_shape, dtype=torch.float32, device=x.device)
     if gw.numel() != g.w_numel():
         raise _hip.HipError("weight gradient shape %s does not match the geometry" % (tuple(w_shape),))
+    if _h_contraction(2, g, gy, x, F32) and (gy.dtype == BF16 or x.dtype == BF16):
+        gh, xh = _cast_raw(gy, BF16), _cast_raw(x, BF16)
+        nbytes = _hip.load().vg_conv2d_wgrad_workspace_bytes(ctypes.byref(g.c))
+        wsp = ctypes.c_void_p(workspace(nbytes, x.device).data_ptr()) if nbytes else None
+        _launch_conv(2, g, lambda: call("vg_conv2d_wgrad_partial_h", ctypes.byref(g.c), _p(gh), _p(xh), _ptr(gw), wsp,
+                                        c_size_t(nbytes), _stream()))
+        if nbytes:
+            call("vg_conv2d_wgrad_reduce", ctypes.byref(g.c), _ptr(gw), wsp, _stream())
+        return gw
+    gy, x = _f32(gy), _f32(x)
     nbytes, wsp = _conv_workspace(2, g, x.device)
     gp, xp = plane_cache.pointer(2, g, gy), plane_cache.pointer(2, g, x)
     _launch_conv(2, g, lambda: call("vg_conv2d_wgrad_partial_prec", ctypes.byref(g.c), _ptr(gy), _ptr(x), _ptr(gw), wsp,
@@ -560,7 +721,7 @@ def raw_colsum(x):
     out = torch.empty(c, dtype=torch.float32, device=x.device)
     nbytes = _hip.load().vg_colsum_workspace_bytes(m, c)
     ws = workspace(nbytes, x.device)
-    call("vg_colsum", _ptr(x), _ptr(out), m, c, ctypes.c_void_p(ws.data_ptr()), c_size_t(nbytes), _stream())
+    call(_A("vg_colsum", x), _p(x), _ptr(out), m, c, ctypes.c_void_p(ws.data_ptr()), c_size_t(nbytes), _stream())
     return out
 
 
@@ -608,7 +769,7 @@ class ConvFwdFn(Function):
         params = not inputs_only.active
         gx = None
         if _wants_input_grad(ctx, x):
-            gx = _input_gradient(ctx, gy, w, x, g, lab)
+            gx = _stored_like(_input_gradient(ctx, gy, w, x, g, lab), x)
         gw = ConvWgradFn.apply(gy, x, g, tuple(w.shape), lab + (1,)) if (params and ctx.needs_input_grad[1]) else None
         gb = ColSumFn.apply(gy) if (params and bias is not None and ctx.needs_input_grad[2]) else None
         return gx, grads.route(w, lab, gw), grads.route(bias, lab, gb), None, None
@@ -625,9 +786,11 @@ class ConvActFn(Function):
         _check_shape(xm, g.x_shape(), "conv input")
         if wm.numel() != g.w_numel():
             raise _hip.HipError("weight has %d elements, geometry expects %d" % (wm.numel(), g.w_numel()))
+        xm = _f32(xm)
         y = _new_act(g.N, g.Co, g.Ho, g.Wo, xm, g.flat)
         _launch_conv(0, g, lambda: call("vg_conv2d_fwd_act", ctypes.byref(g.c), _ptr(xm), _ptr(wm), _ptr(bias), _ptr(y),
                                         act, c_float(slope), _stream()))
+        y = _cast_raw(y, _feature_dtype(g.Co))
         ctx.g, ctx.act, ctx.slope = g, act, slope
         ctx.label = grads.ticket()
         ctx.norm_src = norm_bwd.source_of(x)
@@ -643,7 +806,7 @@ class ConvActFn(Function):
         masked = ctx.consumer is not None and ctx.consumer["accepted"]
         gpre = gy if masked else ActBwdFn.apply(gy, y, ctx.act, ctx.slope)
         params = not inputs_only.active
-        gx = _input_gradient(ctx, gpre, w, x, g, lab) if _wants_input_grad(ctx, x) else None
+        gx = _stored_like(_input_gradient(ctx, gpre, w, x, g, lab), x) if _wants_input_grad(ctx, x) else None
         gw = ConvWgradFn.apply(gpre, x, g, tuple(w.shape), lab + (1,)) if (params and ctx.needs_input_grad[1]) else None
         gb = ColSumFn.apply(gpre) if (params and bias is not None and ctx.needs_input_grad[2]) else None
         return gx, grads.route(w, lab, gw), grads.route(bias, lab, gb), None, None, None
@@ -668,7 +831,7 @@ class ConvDgradFn(Function):
         d_gy = None
         if _wants_input_grad(ctx, gy):
             norm_bwd.request(ctx.norm_src)
-            d_gy = ConvFwdFn.apply(ggx, w, None, g, lab + (0,))
+            d_gy = _stored_like(ConvFwdFn.apply(ggx, w, None, g, lab + (0,)), gy)
             norm_bwd.cancel()
         d_w = ConvWgradFn.apply(gy, ggx, g, tuple(w.shape), lab + (1,)) if (params and ctx.needs_input_grad[1]) else None
         d_b = ColSumFn.apply(ggx) if (params and bias is not None and ctx.needs_input_grad[2]) else None
@@ -726,8 +889,8 @@ class ConvWgradFn(Function):
     def backward(ctx, ggw):
         gy, x = ctx.saved_tensors
         g, lab = ctx.g, ctx.label
-        d_gy = ConvFwdFn.apply(x, ggw, None, g, lab + (0,)) if ctx.needs_input_grad[0] else None
-        d_x = ConvDgradFn.apply(gy, ggw, None, g, lab + (1,)) if ctx.needs_input_grad[1] else None
+        d_gy = _stored_like(ConvFwdFn.apply(x, ggw, None, g, lab + (0,)), gy) if ctx.needs_input_grad[0] else None
+        d_x = _stored_like(ConvDgradFn.apply(gy, ggw, None, g, lab + (1,)), x) if ctx.needs_input_grad[1] else None
         return d_gy, d_x, None, None, None
 
 
@@ -737,6 +900,7 @@ class ColSumFn(Function):
     @staticmethod
     def forward(ctx, x):
         ctx.shape = tuple(x.shape)
+        ctx.dtype = x.dtype
         return raw_colsum(x)
 
     @staticmethod
@@ -750,7 +914,7 @@ class ColSumFn(Function):
             out = torch.empty(shape, dtype=torch.float32, device=like.device)
             m, c = shape
         call("vg_bcast_rows", _ptr(gout.contiguous()), _ptr(out), m, c, _stream())
-        return out
+        return _cast_raw(out, ctx.dtype)
 
 
 def conv2d(x, w, bias, stride, padding, act=_hip.ACT_NONE, slope=0.0):
@@ -820,8 +984,9 @@ class AddFn(Function):
         b = _match_layout(_dense_like(b), a)
         if a.shape != b.shape:
             raise _hip.HipError("sum operands differ in shape: %s vs %s" % (tuple(a.shape), tuple(b.shape)))
+        b = _cast_raw(b, a.dtype)
         out = torch.empty_like(a)
-        call("vg_add", _ptr(a), _ptr(b), _ptr(out), c_size_t(a.numel()), _stream())
+        call(_A("vg_add", a), _p(a), _p(b), _p(out), c_size_t(a.numel()), _stream())
         return out
 
     @staticmethod
@@ -858,11 +1023,11 @@ class BatchNormTrainFn(Function):
                      c_float(eps), c_float(momentum), _ptr(mean), _ptr(invstd), _ptr(running_mean), _ptr(running_var),
                      counter, _stream())
             else:
-                call("vg_bn_stats", _ptr(x), m, c, c_float(eps), c_float(momentum), _ptr(mean), _ptr(invstd),
+                call(_A("vg_bn_stats", x), _p(x), m, c, c_float(eps), c_float(momentum), _ptr(mean), _ptr(invstd),
                      _ptr(running_mean), _ptr(running_var), counter,
                      ctypes.c_void_p(ws.data_ptr()), c_size_t(nbytes), _stream())
         y = torch.empty_like(x)
-        call("vg_bn_apply", _ptr(x), _ptr(mean), _ptr(invstd), _ptr(gamma), _ptr(beta), _ptr(y), m, c,
+        call(_A("vg_bn_apply", x), _p(x), _ptr(mean), _ptr(invstd), _ptr(gamma), _ptr(beta), _p(y), m, c,
              act, c_float(slope), _stream())
         ctx.act, ctx.slope = act, slope
         ctx.label = grads.ticket()
@@ -902,6 +1067,7 @@ class BatchNormBwdFn(Function):
         ctx.label = _label(label)
         left = norm_bwd.claim(gy, mean)
         gy, x = to_nhwc(gy), to_nhwc(x)
+        gy = _cast_raw(gy, x.dtype)
         m, c = _rows_cols(x)
         mask = _act_args(act, slope)
         sums = torch.empty((2, c), dtype=torch.float32, device=x.device)
@@ -910,10 +1076,10 @@ class BatchNormBwdFn(Function):
                  _ptr(sums), _stream())
         else:
             ws, nbytes = _bn_ws(m, c, x.device)
-            call("vg_bn_bwd_reduce", _ptr(gy), _ptr(x), _ptr(mean), _ptr(invstd), m, c, _ptr(sums),
+            call(_A("vg_bn_bwd_reduce", x), _p(gy), _p(x), _ptr(mean), _ptr(invstd), m, c, _ptr(sums),
                  ctypes.c_void_p(ws.data_ptr()), c_size_t(nbytes), *mask, _ptr(gamma), _ptr(mask_beta), _stream())
         gx = torch.empty_like(x)
-        call("vg_bn_bwd_apply", _ptr(gy), _ptr(x), _ptr(mean), _ptr(invstd), _ptr(gamma), _ptr(sums), _ptr(gx), m, c,
+        call(_A("vg_bn_bwd_apply", x), _p(gy), _p(x), _ptr(mean), _ptr(invstd), _ptr(gamma), _ptr(sums), _p(gx), m, c,
              *mask, _ptr(mask_beta), _stream())
         ctx.set_materialize_grads(False)
         return gx, sums[1], sums[0]
@@ -922,27 +1088,29 @@ class BatchNormBwdFn(Function):
     @once_differentiable
     def backward(ctx, u, v, w):
         gy, x, gamma, mean, invstd, mask_beta = ctx.saved_tensors
+        gy_dtype = gy.dtype
         gy, x = to_nhwc(gy), to_nhwc(x)
+        gy = _cast_raw(gy, x.dtype)
         m, c = _rows_cols(x)
         mask = _act_args(ctx.act, ctx.slope)
         if u is None:
             u = torch.empty_like(x)
-            call("vg_fill", _ptr(u), c_float(0.0), c_size_t(u.numel()), _stream())
-        u = to_nhwc(u)
+            call(_A("vg_fill", x), _p(u), c_float(0.0), c_size_t(u.numel()), _stream())
+        u = _cast_raw(to_nhwc(u), x.dtype)
         v = v.contiguous() if v is not None else None
         w = w.contiguous() if w is not None else None
         sums5 = torch.empty((5, c), dtype=torch.float32, device=x.device)
         ws, nbytes = _bn_ws(m, c, x.device)
-        call("vg_bn_dbwd_reduce", _ptr(gy), _ptr(x), _ptr(u), _ptr(mean), _ptr(invstd), m, c, _ptr(sums5),
+        call(_A("vg_bn_dbwd_reduce", x), _p(gy), _p(x), _p(u), _ptr(mean), _ptr(invstd), m, c, _ptr(sums5),
              ctypes.c_void_p(ws.data_ptr()), c_size_t(nbytes), *mask, _ptr(gamma), _ptr(mask_beta), _stream())
         d_gy = torch.empty_like(x)
         d_x = torch.empty_like(x)
         d_gamma = torch.empty(c, dtype=torch.float32, device=x.device) if gamma is not None else None
-        call("vg_bn_dbwd_apply", _ptr(gy), _ptr(x), _ptr(u), _ptr(v), _ptr(w), _ptr(mean), _ptr(invstd), _ptr(gamma),
-             _ptr(sums5), _ptr(d_gy), _ptr(d_x), _ptr(d_gamma), m, c, *mask, _ptr(mask_beta), _stream())
+        call(_A("vg_bn_dbwd_apply", x), _p(gy), _p(x), _p(u), _ptr(v), _ptr(w), _ptr(mean), _ptr(invstd), _ptr(gamma),
+             _ptr(sums5), _p(d_gy), _p(d_x), _ptr(d_gamma), m, c, *mask, _ptr(mask_beta), _stream())
         if gamma is not None:
             d_gamma = grads.route(gamma, ctx.label, d_gamma)
-        return d_gy, d_x, d_gamma, None, None, None, None, None, None
+        return _cast_raw(d_gy, gy_dtype), d_x, d_gamma, None, None, None, None, None, None
 
 
 class BatchNormEvalFn(Function):
@@ -953,7 +1121,7 @@ class BatchNormEvalFn(Function):
         invstd = torch.empty(c, dtype=torch.float32, device=x.device)
         call("vg_bn_invstd_from_var", _ptr(running_var), _ptr(invstd), c, c_float(eps), _stream())
         y = torch.empty_like(x)
-        call("vg_bn_apply", _ptr(x), _ptr(running_mean), _ptr(invstd), _ptr(gamma), _ptr(beta), _ptr(y), m, c,
+        call(_A("vg_bn_apply", x), _p(x), _ptr(running_mean), _ptr(invstd), _ptr(gamma), _ptr(beta), _p(y), m, c,
              act, c_float(slope), _stream())
         ctx.act, ctx.slope = act, slope
         ctx.label = grads.ticket()
@@ -965,19 +1133,19 @@ class BatchNormEvalFn(Function):
     @once_differentiable
     def backward(ctx, gy):
         x, gamma, beta, mean, invstd, y = ctx.saved_tensors
-        gy = to_nhwc(gy)
+        gy = _cast_raw(to_nhwc(gy), x.dtype)
         m, c = _rows_cols(x)
         if y is not None:  # undo the fused activation first: g = gy * act'(y)
             g = torch.empty_like(x)
-            call("vg_act_bwd", _ptr(gy), _ptr(y), _ptr(g), c_size_t(x.numel()), ctx.act, c_float(ctx.slope), _stream())
+            call(_A("vg_act_bwd", x), _p(gy), _p(y), _p(g), c_size_t(x.numel()), ctx.act, c_float(ctx.slope), _stream())
             gy = g
         gx = torch.empty_like(x)
-        call("vg_bn_bwd_eval", _ptr(gy), _ptr(invstd), _ptr(gamma), _ptr(gx), m, c, _stream())
+        call(_A("vg_bn_bwd_eval", x), _p(gy), _ptr(invstd), _ptr(gamma), _p(gx), m, c, _stream())
         ggamma = gbeta = None
         if ctx.has_affine[0] or ctx.has_affine[1]:
             sums = torch.empty((2, c), dtype=torch.float32, device=x.device)
             ws, nbytes = _bn_ws(m, c, x.device)
-            call("vg_bn_bwd_reduce", _ptr(gy), _ptr(x), _ptr(mean), _ptr(invstd), m, c, _ptr(sums),
+            call(_A("vg_bn_bwd_reduce", x), _p(gy), _p(x), _ptr(mean), _ptr(invstd), m, c, _ptr(sums),
                  ctypes.c_void_p(ws.data_ptr()), c_size_t(nbytes), None, _hip.ACT_NONE, c_float(0.0), None, None,
                  _stream())
             ggamma = grads.route(gamma, ctx.label, sums[1]) if ctx.has_affine[0] else None
@@ -1017,7 +1185,7 @@ class ActFn(Function):
         x_in = x
         x = _dense_like(x)
         y = torch.empty_like(x)
-        call("vg_act_fwd", _ptr(x), _ptr(y), c_size_t(x.numel()), act, c_float(slope), _stream())
+        call(_A("vg_act_fwd", x), _p(x), _p(y), c_size_t(x.numel()), act, c_float(slope), _stream())
         ctx.act, ctx.slope = act, slope
         # ReLU / LeakyReLU in front of a convolution that may return its input gradient already masked
         ctx.consumer = act_grad.take_token() if act in (_hip.ACT_RELU, _hip.ACT_LRELU) and slope >= 0 else None
@@ -1040,9 +1208,9 @@ class ActBwdFn(Function):
         ctx.act, ctx.slope = act, slope
         ctx.save_for_backward(gy, ref)
         ref = _dense_like(ref)
-        gy = _match_layout(_dense_like(gy), ref)
+        gy = _cast_raw(_match_layout(_dense_like(gy), ref), ref.dtype)
         gx = torch.empty_like(ref)
-        call("vg_act_bwd", _ptr(gy), _ptr(ref), _ptr(gx), c_size_t(ref.numel()), act, c_float(slope), _stream())
+        call(_A("vg_act_bwd", ref), _p(gy), _p(ref), _p(gx), c_size_t(ref.numel()), act, c_float(slope), _stream())
         return gx
 
     @staticmethod
@@ -1054,10 +1222,10 @@ class ActBwdFn(Function):
             if torch.is_grad_enabled():
                 raise NotImplementedError("third-order derivatives of tanh/sigmoid are not implemented")
             ref_ = _dense_like(ref)
-            gg_ = _match_layout(_dense_like(gg), ref_)
-            gy_ = _match_layout(_dense_like(gy), ref_)
+            gg_ = _cast_raw(_match_layout(_dense_like(gg), ref_), ref_.dtype)
+            gy_ = _cast_raw(_match_layout(_dense_like(gy), ref_), ref_.dtype)
             d_ref = torch.empty_like(ref_)
-            call("vg_act_dbwd_ref", _ptr(gg_), _ptr(gy_), _ptr(ref_), _ptr(d_ref), c_size_t(ref_.numel()), ctx.act,
+            call(_A("vg_act_dbwd_ref", ref_), _p(gg_), _p(gy_), _p(ref_), _p(d_ref), c_size_t(ref_.numel()), ctx.act,
                  _stream())
         return d_gy, d_ref, None, None
 
@@ -1085,7 +1253,8 @@ def _iptr(t):
 class MaxPoolFn(Function):
     @staticmethod
     def forward(ctx, x, kernel, stride, padding):
-        x = to_nhwc(x)
+        ctx.dtype = x.dtype
+        x = _f32(to_nhwc(x))
         n, c, h, w = x.shape
         g = Geom(n, h, w, c, c, kernel[0], kernel[1], stride[0], stride[1], padding[0], padding[1])
         y = _new_act(n, c, g.Ho, g.Wo, x, False)
@@ -1099,7 +1268,8 @@ class MaxPoolFn(Function):
     @staticmethod
     def backward(ctx, gy):
         (idx,) = ctx.saved_tensors
-        return MaxPoolBwdFn.apply(gy, idx, ctx.g), None, None, None
+        gx = MaxPoolBwdFn.apply(gy, idx, ctx.g)
+        return (gx if gx.dtype == ctx.dtype else CastFn.apply(gx, ctx.dtype)), None, None, None
 
 
 class MaxPoolBwdFn(Function):
@@ -1107,7 +1277,7 @@ class MaxPoolBwdFn(Function):
 
     @staticmethod
     def forward(ctx, gy, idx, g):
-        gy = to_nhwc(gy)
+        gy = _f32(to_nhwc(gy))
         _check_shape(gy, (g.N, g.Ci, g.Ho, g.Wo), "pooling output-side tensor")
         gx = _new_act(g.N, g.Ci, g.H, g.W, gy, False)
         call("vg_maxpool2d_bwd", ctypes.byref(g.c), _ptr(gy), _iptr(idx), _ptr(gx), _stream())
@@ -1120,7 +1290,7 @@ class MaxPoolBwdFn(Function):
     def backward(ctx, ggx):
         (idx,) = ctx.saved_tensors
         g = ctx.g
-        ggx = to_nhwc(ggx)
+        ggx = _f32(to_nhwc(ggx))
         out = _new_act(g.N, g.Ci, g.Ho, g.Wo, ggx, False)
         call("vg_maxpool2d_pick", ctypes.byref(g.c), _ptr(ggx), _iptr(idx), _ptr(out), _stream())
         return out, None, None
@@ -1141,9 +1311,9 @@ def _reduce_ws(n, device):
 def _flat_dense(t):
     """`t` as one gap-free block the loss kernels can walk as flat memory (a channel / column slice is compacted)."""
     _require_gpu(t)
-    if t.is_contiguous() or t.is_contiguous(memory_format=CL):
-        return t
-    return _plain_contiguous(t)
+    if not (t.is_contiguous() or t.is_contiguous(memory_format=CL)):
+        t = _plain_contiguous(t)
+    return _f32(t)      # (network outputs arrive as f32; a bf16 tensor handed in directly is widened)
 
 
 class MeanLossFn(Function):

@@ -10,6 +10,7 @@ import torch
 from torch import nn
 
 from ..engine import modules as hip_modules
+from ..engine import ops as hip_ops
 
 
 class NeuralNetwork(nn.Module):
@@ -36,7 +37,9 @@ class NeuralNetwork(nn.Module):
         self.output_size = self._get_output_shape()[1:]
 
     def forward(self, x):
-        return self.network(x)
+        # what leaves a network is f32 in every precision mode (in the bf16 mode a feature-shaped output is widened
+        # here): losses, the gradient penalty and the caller only ever see f32
+        return hip_ops.as_f32(self.network(x))
 
     # -- checks -------------------------------------------------------------------------------------------
     def _get_iterative_layers(self):

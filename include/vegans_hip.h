@@ -365,6 +365,52 @@ int vg_sgd_step(float* param, const float* grad, float* momentum_buf, size_t n, 
 /* p = min(max(p, lo), hi), NaN preserved (torch clamp_) */
 int vg_clamp(float* param, size_t n, float lo, float hi, void* stream);
 
+/* ---- activations stored as bf16 ("_h" entry points) ---------------------------------------------------------------
+ * The bf16 mode named beside fp32 in the reference-facing configuration (torch autocast / bf16 tensors where the
+ * reference would call nn.Conv2d / nn.BatchNorm2d / nn.LeakyReLU on them; the reference itself, utils/networks.py:19-154,
+ * only ever runs f32) as a DATA PATH: feature maps and their gradients live in HBM as bf16 (round to nearest even on
+ * every store), parameters, their gradients, optimizer state, batch statistics, per-channel sums and losses stay f32,
+ * and all arithmetic between a load and a store is f32. bf16 tensors cross this interface as void*; their memory
+ * order is that of the f32 entry point of the same name (NHWC activations, [Co][kh][kw][Ci] weights). Weights are
+ * handed over as a bf16 copy of the f32 master (vg_cast_f32_to_bf16, once per parameter update).
+ * vg_conv2d_h_applies(mode, g) tells whether contraction `mode` (0 fwd, 1 dgrad, 2 wgrad) of geometry g runs on bf16
+ * tensors (channel counts in multiples of 8, more than 32 GEMM columns, not one of the thin / stem / 1x1 special
+ * kernels); other shapes go through the f32 entry points on converted copies. No workspace except the split-K slabs
+ * of the weight gradient (vg_conv2d_wgrad_workspace_bytes; vg_conv2d_wgrad_reduce adds them as for f32). */
+int vg_conv2d_h_applies(int mode, const vg_conv_geom* g);
+int vg_conv2d_fwd_h(const vg_conv_geom* g, const void* x, const void* w, const float* bias, void* y, void* stream);
+int vg_conv2d_dgrad_h(const vg_conv_geom* g, const void* gy, const void* w, const float* bias, void* gx, void* stream);
+int vg_conv2d_wgrad_partial_h(const vg_conv_geom* g, const void* gy, const void* x, float* gw, void* workspace,
+                              size_t workspace_bytes, void* stream);
+int vg_cast_f32_to_bf16(const float* in, void* out, size_t n, void* stream);
+int vg_cast_bf16_to_f32(const void* in, float* out, size_t n, void* stream);
+int vg_add_h(const void* a, const void* b, void* out, size_t n, void* stream);
+int vg_fill_h(void* out, float v, size_t n, void* stream);
+int vg_colsum_h(const void* x, float* out, int M, int C, void* workspace, size_t workspace_bytes, void* stream);
+/* BatchNorm and activation kernels on bf16 activations: arguments as in the f32 entry points of the same name */
+int vg_bn_stats_h(const void* x, int M, int C, float eps, float momentum, float* mean, float* invstd,
+                  float* running_mean, float* running_var, long long* num_batches_tracked, void* workspace,
+                  size_t workspace_bytes, void* stream);
+int vg_bn_apply_h(const void* x, const float* mean, const float* invstd, const float* gamma, const float* beta, void* y,
+                  int M, int C, int act, float slope, void* stream);
+int vg_bn_bwd_reduce_h(const void* gy, const void* x, const float* mean, const float* invstd, int M, int C, float* sums,
+                       void* workspace, size_t workspace_bytes, const void* act_out, int act, float slope,
+                       const float* gamma, const float* beta, void* stream);
+int vg_bn_bwd_apply_h(const void* gy, const void* x, const float* mean, const float* invstd, const float* gamma,
+                      const float* sums, void* gx, int M, int C, const void* act_out, int act, float slope,
+                      const float* beta, void* stream);
+int vg_bn_bwd_eval_h(const void* gy, const float* invstd, const float* gamma, void* gx, int M, int C, void* stream);
+int vg_bn_dbwd_reduce_h(const void* gy, const void* x, const void* u, const float* mean, const float* invstd, int M,
+                        int C, float* sums5, void* workspace, size_t workspace_bytes, const void* act_out, int act,
+                        float slope, const float* gamma, const float* beta, void* stream);
+int vg_bn_dbwd_apply_h(const void* gy, const void* x, const void* u, const float* v, const float* w, const float* mean,
+                       const float* invstd, const float* gamma, const float* sums5, void* d_gy, void* d_x,
+                       float* d_gamma, int M, int C, const void* act_out, int act, float slope, const float* beta,
+                       void* stream);
+int vg_act_fwd_h(const void* x, void* y, size_t n, int act, float slope, void* stream);
+int vg_act_bwd_h(const void* gy, const void* ref, void* gx, size_t n, int act, float slope, void* stream);
+int vg_act_dbwd_ref_h(const void* gg, const void* gy, const void* ref, void* d_ref, size_t n, int act, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -83,7 +83,8 @@ BF16_CASES = [
 
 @pytest.mark.parametrize("case", BF16_CASES)
 def test_bf16_mode_is_exact_on_bf16_representable_operands(gpu, case):
-    """bf16 mode rounds the operands to bf16 inside the kernel and accumulates their exact products in f32. Fed with
+    """(The "bf16_compute" mode: f32 tensors, bf16 matrix operands; the bf16 data path has tests/test_bf16_storage_gpu.py.)
+    bf16 mode rounds the operands to bf16 inside the kernel and accumulates their exact products in f32. Fed with
     operands that already are bf16 values, every contraction (forward, input gradient, weight gradient) must therefore
     agree with torch's f32 result to summation-order noise, like the f32 kernels do."""
     from vegans.engine import ops
@@ -103,7 +104,7 @@ def test_bf16_mode_is_exact_on_bf16_representable_operands(gpu, case):
     yr = ref(xr, wr)
     gy = rnd(torch.randn(yr.shape, generator=g))
     yr.backward(gy)
-    previous = ops.set_matmul_precision("bf16")
+    previous = ops.set_matmul_precision("bf16_compute")
     try:
         xd, wd = x.to(gpu).requires_grad_(True), w.to(gpu).requires_grad_(True)
         y = dut(xd, wd)
@@ -124,7 +125,7 @@ def test_bf16_mode_rounds_operands_to_nearest_even(gpu):
     w = torch.randn(64, 32, 3, 3, generator=g) * 0.1
     want = F.conv2d(x.bfloat16().float(), w.bfloat16().float(), None, stride=1, padding=1)
     exact = F.conv2d(x, w, None, stride=1, padding=1)
-    previous = ops.set_matmul_precision("bf16")
+    previous = ops.set_matmul_precision("bf16_compute")
     try:
         got = ops.conv2d(x.to(gpu), w.to(gpu), None, (1, 1), (1, 1))
     finally:

@@ -63,7 +63,7 @@ def main():
                       lambda: torch.autograd.grad(F.conv2d(x, wt, None, 2, 1), wt, gy)[0]),
         }
         for mode, (fn, ref, torch_fn) in cases.items():
-            for prec in ("fp32", "fp32_split", "bf16"):
+            for prec in ("fp32", "fp32_split", "bf16_compute"):
                 previous = ops.set_matmul_precision(prec)
                 try:
                     out, us = timed(fn, reps)
