@@ -154,8 +154,19 @@ __global__ void __launch_bounds__(256) dgrad_thin_kernel(const float* __restrict
 // output pixel of the block's tile add up the (at most ceil(KH/sh)*ceil(KW/sw)) partials that land on it, in tap
 // order. A tile is RH x RW gy pixels; neighbouring tiles overlap by ceil(K/s)-1 rows/columns so that every output
 // pixel finds all its partials inside one tile (no atomics); a tile that spans a whole dimension needs no overlap.
-template <int CI, int TAPS>
-__global__ void __launch_bounds__(256) dgrad_scatter_kernel(const float* __restrict__ gy, const float* __restrict__ w,
+// four consecutive values of a tensor stored as f32 or as bf16 (widened: a shift)
+__device__ __forceinline__ f32x4 vg_ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+__device__ __forceinline__ f32x4 vg_ld4(const __bf16* p) {
+  const u32x2 t = *reinterpret_cast<const u32x2*>(p);
+  const f32x4 v = {__builtin_bit_cast(float, t[0] << 16), __builtin_bit_cast(float, t[0] & 0xffff0000u),
+                   __builtin_bit_cast(float, t[1] << 16), __builtin_bit_cast(float, t[1] & 0xffff0000u)};
+  return v;
+}
+
+// TG: storage type of the gradient that comes in (f32, or bf16 when the feature maps of the network are stored as bf16;
+// the image-sized result is f32 either way)
+template <int CI, int TAPS, class TG = float>
+__global__ void __launch_bounds__(256) dgrad_scatter_kernel(const TG* __restrict__ gy, const float* __restrict__ w,
                                                             const float* __restrict__ bias, float* __restrict__ gx, int H,
                                                             int W, int Co, int KH, int KW, int Ho, int Wo, int sh, int sw,
                                                             int ph, int pw, int RW, int tiles_h, int tiles_w, int step_h,
@@ -212,7 +223,7 @@ __global__ void __launch_bounds__(256) dgrad_scatter_kernel(const float* __restr
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (src[j] >= 0 && cc0 + 4 * (int)(threadIdx.x & 7) < Co) v = *reinterpret_cast<const f32x4*>(gy + src[j] + cc0);
+        if (src[j] >= 0 && cc0 + 4 * (int)(threadIdx.x & 7) < Co) v = vg_ld4(gy + src[j] + cc0);
         pre[j] = v;
       }
     };
@@ -259,12 +270,12 @@ __global__ void __launch_bounds__(256) dgrad_scatter_kernel(const float* __restr
         }
       }
   } else if (mine) {
-    const float* g = gy + ((size_t)(n * Ho + ho) * Wo + wo) * Co;
+    const TG* g = gy + ((size_t)(n * Ho + ho) * Wo + wo) * Co;
     // the next quad of channels is fetched while the current one is being used
-    f32x4 gv = *reinterpret_cast<const f32x4*>(g);
+    f32x4 gv = vg_ld4(g);
     for (int co = 0; co < Co; co += 4) {
       const int nx = co + 4 < Co ? co + 4 : co;
-      const f32x4 gn = *reinterpret_cast<const f32x4*>(g + nx);
+      const f32x4 gn = vg_ld4(g + nx);
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const float* wc = w + (size_t)(co + e) * NP;
@@ -386,9 +397,10 @@ namespace {
 // window leaves the image), and every lane reads its A values of v_mfma_f32_32x32x2_f32 from the patch at compile-time
 // offsets, while the weight fragments of the block's 64 output channels stay in registers. A block is 4 waves; wave v
 // owns output row ho0 + v of the tile, 32 consecutive output columns; blockIdx.y walks the channel tiles.
-template <int CI, int KK, int S>
+// TO: storage type of the result (f32, or bf16 rounded to nearest even at the store).
+template <int CI, int KK, int S, class TO = float>
 __global__ void __launch_bounds__(256) stem_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
-                                                       const float* __restrict__ bias, float* __restrict__ y, int H, int W,
+                                                       const float* __restrict__ bias, TO* __restrict__ y, int H, int W,
                                                        int Co, int Ho, int Wo, int ph, int pw, int tiles_w, int tiles_h,
                                                        int tiles_total, int act, float slope) {
   constexpr int K = KK * KK * CI, KP = (K + 1) / 2;
@@ -513,7 +525,7 @@ __global__ void __launch_bounds__(256) stem_fwd_kernel(const float* __restrict__
     if (ho < Ho) {
       // lane (r, h) owns channel co0 + 32 t + r of pixels wo0 + 4 h + {0..3} + 8 g: one 64-bit base per tile, then
       // offsets that are compile-time multiples of Co
-      float* yb = y + ((size_t)(n * Ho + ho) * Wo + wo0 + 4 * h) * Co + co0 + r;
+      TO* yb = y + ((size_t)(n * Ho + ho) * Wo + wo0 + 4 * h) * Co + co0 + r;
       auto put = [&](auto checked) __attribute__((always_inline)) {
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
@@ -524,7 +536,7 @@ __global__ void __launch_bounds__(256) stem_fwd_kernel(const float* __restrict__
             float v = acc[t][e] + bv[t];
             const float lo = relu ? 0.f : v * neg;
             v = v > 0.f ? v : lo;
-            if (!decltype(checked)::value || wo0 + 4 * h + px < Wo) yb[px * Co + 32 * t] = v;
+            if (!decltype(checked)::value || wo0 + 4 * h + px < Wo) yb[px * Co + 32 * t] = (TO)v;
           }
         }
       };
@@ -547,8 +559,8 @@ __global__ void __launch_bounds__(256) stem_fwd_kernel(const float* __restrict__
 // row v of a 4 x 32 pixel tile) walks tiles blockIdx.x, blockIdx.x + gridDim.x, ... with the next tile's operands in
 // flight, keeps its 64 x K partial result in registers, adds the four waves' parts in wave order through LDS and writes
 // one slab; the slabs are then added in slab order by the split-K reduce of the generic path (same layout and count).
-template <int CI, int KK, int S>
-__global__ void __launch_bounds__(256) stem_wgrad_kernel(const float* __restrict__ gy, const float* __restrict__ x,
+template <int CI, int KK, int S, class TG = float>
+__global__ void __launch_bounds__(256) stem_wgrad_kernel(const TG* __restrict__ gy, const float* __restrict__ x,
                                                          float* __restrict__ slabs, int H, int W, int Co, int Ho, int Wo,
                                                          int ph, int pw, int tiles_w, int tiles_h, int tiles_total) {
   constexpr int K = KK * KK * CI, NT = (K + 15) / 16, KC = KK * CI;
@@ -599,8 +611,8 @@ __global__ void __launch_bounds__(256) stem_wgrad_kernel(const float* __restrict
       const int wo = wo0 + 4 * j + q;
       // an invalid lane reads the zero page: the loaded value itself is not touched, so nothing waits for it here
       const bool ok = ho < Ho && wo < Wo;
-      const float* ptr = ok ? gy + ((size_t)(n * Ho + ho) * Wo + wo) * Co + co0 + 4 * i16 : vg_zero_page;
-      nxt[j] = *reinterpret_cast<const f32x4*>(ptr);
+      const TG* ptr = ok ? gy + ((size_t)(n * Ho + ho) * Wo + wo) * Co + co0 + 4 * i16 : reinterpret_cast<const TG*>(vg_zero_page);
+      nxt[j] = vg_ld4(ptr);
     }
     const int hi0 = th * TH * S - ph, wi0 = tw * TW * S - pw;
     const float* img = x + (size_t)n * H * W * CI;
@@ -679,8 +691,8 @@ __global__ void __launch_bounds__(256) stem_wgrad_kernel(const float* __restrict
     slab[i] = ((red[i] + red[64 * K + i]) + red[2 * 64 * K + i]) + red[3 * 64 * K + i];
 }
 
-int try_fwd_stem(const vg_conv_geom* g, const float* x, const float* w, const float* bias, float* y, hipStream_t st,
-                 int act, float slope) {
+int try_fwd_stem(const vg_conv_geom* g, const float* x, const float* w, const float* bias, void* y, hipStream_t st,
+                 int act, float slope, bool out_h = false) {
   if (!vg_stem_fwd_applies(g)) return 0;
   const int tiles_w = (g->Wo + 31) / 32, tiles_h = (g->Ho + 3) / 4;
   const long long blocks = (long long)tiles_w * tiles_h * g->N;
@@ -692,8 +704,12 @@ int try_fwd_stem(const vg_conv_geom* g, const float* x, const float* w, const fl
   bool done = false;
 #define STEM_FWD(CI_, KK_, S_)                                                                                          \
   if (!done && g->Ci == CI_ && g->kh == KK_ && g->sh == S_) {                                                          \
-    vg_launch_timed(stem_fwd_kernel<CI_, KK_, S_>, grid, dim3(256), 0, st, x, w, bias, y, g->H, g->W, g->Co, g->Ho, \
-                       g->Wo, g->ph, g->pw, tiles_w, tiles_h, (int)blocks, act, slope);                               \
+    if (out_h)                                                                                                         \
+      vg_launch_timed(stem_fwd_kernel<CI_, KK_, S_, __bf16>, grid, dim3(256), 0, st, x, w, bias, (__bf16*)y, g->H,     \
+                      g->W, g->Co, g->Ho, g->Wo, g->ph, g->pw, tiles_w, tiles_h, (int)blocks, act, slope);            \
+    else                                                                                                               \
+      vg_launch_timed(stem_fwd_kernel<CI_, KK_, S_, float>, grid, dim3(256), 0, st, x, w, bias, (float*)y, g->H, g->W, \
+                      g->Co, g->Ho, g->Wo, g->ph, g->pw, tiles_w, tiles_h, (int)blocks, act, slope);                  \
     done = true;                                                                                                       \
   }
   STEM_FWD(3, 4, 2) STEM_FWD(1, 4, 2) STEM_FWD(3, 3, 1) STEM_FWD(1, 3, 1) STEM_FWD(3, 5, 2) STEM_FWD(1, 5, 2)
@@ -712,7 +728,13 @@ int vg_stem_wgrad_applies(const vg_conv_geom* g) {
   return vg_stem_fwd_applies(g) && g->Co % 64 == 0 && g->kh == g->kw && g->sh == g->sw;
 }
 
+static int wgrad_stem(const vg_conv_geom* g, const void* gy, bool gy_h, const float* x, float* slabs, int nslabs, hipStream_t st);
+
 int vg_try_wgrad_stem(const vg_conv_geom* g, const float* gy, const float* x, float* slabs, int nslabs, hipStream_t st) {
+  return wgrad_stem(g, gy, false, x, slabs, nslabs, st);
+}
+
+static int wgrad_stem(const vg_conv_geom* g, const void* gy, bool gy_h, const float* x, float* slabs, int nslabs, hipStream_t st) {
   if (!vg_stem_wgrad_applies(g) || nslabs < 2 || !vg_aligned16(gy)) return 0;
   const int tiles_w = (g->Wo + 31) / 32, tiles_h = (g->Ho + 3) / 4;
   const long long tiles = (long long)tiles_w * tiles_h * g->N;
@@ -721,8 +743,12 @@ int vg_try_wgrad_stem(const vg_conv_geom* g, const float* gy, const float* x, fl
   bool done = false;
 #define STEM_WGRAD(CI_, KK_, S_)                                                                                       \
   if (!done && g->Ci == CI_ && g->kh == KK_ && g->sh == S_) {                                                          \
-    vg_launch_timed(stem_wgrad_kernel<CI_, KK_, S_>, grid, dim3(256), 0, st, gy, x, slabs, g->H, g->W, g->Co,      \
-                       g->Ho, g->Wo, g->ph, g->pw, tiles_w, tiles_h, (int)tiles);                                      \
+    if (gy_h)                                                                                                          \
+      vg_launch_timed(stem_wgrad_kernel<CI_, KK_, S_, __bf16>, grid, dim3(256), 0, st, (const __bf16*)gy, x, slabs,    \
+                      g->H, g->W, g->Co, g->Ho, g->Wo, g->ph, g->pw, tiles_w, tiles_h, (int)tiles);                    \
+    else                                                                                                               \
+      vg_launch_timed(stem_wgrad_kernel<CI_, KK_, S_, float>, grid, dim3(256), 0, st, (const float*)gy, x, slabs,      \
+                      g->H, g->W, g->Co, g->Ho, g->Wo, g->ph, g->pw, tiles_w, tiles_h, (int)tiles);                    \
     done = true;                                                                                                       \
   }
   STEM_WGRAD(3, 4, 2) STEM_WGRAD(1, 4, 2) STEM_WGRAD(3, 3, 1) STEM_WGRAD(1, 3, 1) STEM_WGRAD(3, 5, 2) STEM_WGRAD(1, 5, 2)
@@ -789,8 +815,8 @@ static void scatter_tiling(int extent, int r, int nt, int* tiles, int* step, int
   }
 }
 
-static int try_dgrad_scatter(const vg_conv_geom* g, const float* gy, const float* w, const float* bias, float* gx,
-                             hipStream_t st) {
+static int try_dgrad_scatter(const vg_conv_geom* g, const void* gy, const float* w, const float* bias, float* gx,
+                             hipStream_t st, bool gy_h = false) {
   const int taps = g->kh * g->kw;
   if (g->Ci > 4 || g->Co % 4 != 0 || !vg_aligned16(gy) || !vg_aligned16(w)) return 0;
   if (taps != 9 && taps != 16 && taps != 25) return 0;
@@ -814,10 +840,16 @@ static int try_dgrad_scatter(const vg_conv_geom* g, const float* gy, const float
   const long long grid = best_blocks * g->N;
   if (grid > 0x7fffffffLL) return 0;
 #define THIN_SCATTER(CI_, TAPS_)                                                                                        \
-  if (g->Ci == CI_ && taps == TAPS_)                                                                                    \
-    vg_launch_timed(dgrad_scatter_kernel<CI_, TAPS_>, dim3((unsigned)grid), dim3(256), 0, st, gy, w, bias, gx,      \
-                       g->H, g->W, g->Co, g->kh, g->kw, g->Ho, g->Wo, g->sh, g->sw, g->ph, g->pw, best_rw, bt_h, bt_w,  \
-                       bs_h, bs_w, bo_h, bo_w);
+  if (g->Ci == CI_ && taps == TAPS_) {                                                                                  \
+    if (gy_h)                                                                                                           \
+      vg_launch_timed(dgrad_scatter_kernel<CI_, TAPS_, __bf16>, dim3((unsigned)grid), dim3(256), 0, st,                 \
+                      (const __bf16*)gy, w, bias, gx, g->H, g->W, g->Co, g->kh, g->kw, g->Ho, g->Wo, g->sh, g->sw,      \
+                      g->ph, g->pw, best_rw, bt_h, bt_w, bs_h, bs_w, bo_h, bo_w);                                       \
+    else                                                                                                                \
+      vg_launch_timed(dgrad_scatter_kernel<CI_, TAPS_, float>, dim3((unsigned)grid), dim3(256), 0, st,                  \
+                      (const float*)gy, w, bias, gx, g->H, g->W, g->Co, g->kh, g->kw, g->Ho, g->Wo, g->sh, g->sw,       \
+                      g->ph, g->pw, best_rw, bt_h, bt_w, bs_h, bs_w, bo_h, bo_w);                                       \
+  }
   THIN_SCATTER(1, 9) THIN_SCATTER(2, 9) THIN_SCATTER(3, 9) THIN_SCATTER(4, 9)
   THIN_SCATTER(1, 16) THIN_SCATTER(2, 16) THIN_SCATTER(3, 16) THIN_SCATTER(4, 16)
   THIN_SCATTER(1, 25) THIN_SCATTER(2, 25) THIN_SCATTER(3, 25) THIN_SCATTER(4, 25)
@@ -847,4 +879,56 @@ int vg_try_dgrad_thin(const vg_conv_geom* g, const float* gy, const float* w, co
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return vg_fail(VG_ERR_LAUNCH, "vg_conv2d_dgrad(thin): launch failed: %s", hipGetErrorString(e));
   return 1;
+}
+
+// ---- image stems of a network whose feature maps are stored as bf16 -----------------------------------------------------
+// The layers next to an image (the critic's first convolution, the generator's last transposed convolution) have an f32
+// image on one side and a bf16 feature map on the other: forward f32 x -> bf16 y (optionally through ReLU / LeakyReLU),
+// input gradient bf16 gy -> f32 gx, weight gradient from bf16 gy and f32 x. Same kernels as the f32 entry points, the
+// feature-map side loaded / stored in its storage type.
+extern "C" int vg_conv2d_stem_h_applies(int mode, const vg_conv_geom* g) {
+  if (vg_check_geom(g, "vg_conv2d_stem_h_applies") || mode < 0 || mode > 2) return 0;
+  if (mode == 0) return vg_stem_fwd_applies(g);
+  if (mode == 1) {
+    const int taps = g->kh * g->kw;
+    const bool gemm = g->Ho == 1 && g->Wo == 1 && g->ph == 0 && g->pw == 0 && g->H == g->kh && g->W == g->kw;
+    return !gemm && g->Ci <= 4 && g->Co % 4 == 0 && (taps == 9 || taps == 16 || taps == 25);
+  }
+  return vg_stem_wgrad_applies(g) && vg_conv2d_wgrad_workspace_bytes(g) > 0;
+}
+
+extern "C" int vg_conv2d_stem_fwd_h(const vg_conv_geom* g, const float* x, const float* w, const float* bias, void* y,
+                                    int act, float slope, void* stream) {
+  if (!vg_conv2d_stem_h_applies(0, g))
+    return vg_fail(VG_ERR_INVALID, "vg_conv2d_stem_fwd_h: not an image stem the stem kernel serves (vg_conv2d_stem_h_applies)");
+  VG_REQUIRE(x && w && y, "vg_conv2d_stem_fwd_h: null tensor pointer");
+  VG_REQUIRE(act == VG_ACT_NONE || act == VG_ACT_RELU || act == VG_ACT_LRELU, "vg_conv2d_stem_fwd_h: only ReLU / LeakyReLU can be fused");
+  const int r = try_fwd_stem(g, x, w, bias, y, (hipStream_t)stream, act, slope, true);
+  if (r == 0) return vg_fail(VG_ERR_INVALID, "vg_conv2d_stem_fwd_h: geometry too large for the stem kernel");
+  return r < 0 ? r : VG_OK;
+}
+
+extern "C" int vg_conv2d_stem_dgrad_h(const vg_conv_geom* g, const void* gy, const float* w, const float* bias, float* gx,
+                                      void* stream) {
+  if (!vg_conv2d_stem_h_applies(1, g))
+    return vg_fail(VG_ERR_INVALID, "vg_conv2d_stem_dgrad_h: geometry not served (vg_conv2d_stem_h_applies)");
+  VG_REQUIRE(gy && w && gx && vg_aligned16(gy) && vg_aligned16(w), "vg_conv2d_stem_dgrad_h: null or misaligned tensor");
+  const int r = try_dgrad_scatter(g, gy, w, bias, gx, (hipStream_t)stream, true);
+  if (r == 0) return vg_fail(VG_ERR_INVALID, "vg_conv2d_stem_dgrad_h: no tile shape for this geometry");
+  return r < 0 ? r : VG_OK;
+}
+
+extern "C" int vg_conv2d_stem_wgrad_partial_h(const vg_conv_geom* g, const void* gy, const float* x, void* workspace,
+                                              size_t workspace_bytes, void* stream) {
+  if (!vg_conv2d_stem_h_applies(2, g))
+    return vg_fail(VG_ERR_INVALID, "vg_conv2d_stem_wgrad_partial_h: geometry not served (vg_conv2d_stem_h_applies)");
+  const size_t need = vg_conv2d_wgrad_workspace_bytes(g);
+  VG_REQUIRE(gy && x && vg_aligned16(gy), "vg_conv2d_stem_wgrad_partial_h: null or misaligned tensor");
+  if (!workspace || workspace_bytes < need || !vg_aligned16(workspace))
+    return vg_fail(VG_ERR_WORKSPACE, "vg_conv2d_stem_wgrad_partial_h: workspace of %zu bytes (16-byte aligned) required, got %zu",
+                   need, workspace_bytes);
+  const int nslabs = (int)(need / ((size_t)g->Co * g->kh * g->kw * g->Ci * sizeof(float)));
+  const int r = wgrad_stem(g, gy, true, x, (float*)workspace, nslabs, (hipStream_t)stream);
+  if (r == 0) return vg_fail(VG_ERR_INVALID, "vg_conv2d_stem_wgrad_partial_h: geometry too large for the stem kernel");
+  return r < 0 ? r : VG_OK;
 }

@@ -127,6 +127,10 @@ SIGNATURES = {
     "vg_conv2d_fwd_h": (c_int, [_G, _P, _P, _P, _P, _P]),
     "vg_conv2d_dgrad_h": (c_int, [_G, _P, _P, _P, _P, _P]),
     "vg_conv2d_wgrad_partial_h": (c_int, [_G, _P, _P, _P, _P, c_size_t, _P]),
+    "vg_conv2d_stem_h_applies": (c_int, [c_int, _G]),
+    "vg_conv2d_stem_fwd_h": (c_int, [_G, _P, _P, _P, _P, c_int, c_float, _P]),
+    "vg_conv2d_stem_dgrad_h": (c_int, [_G, _P, _P, _P, _P, _P]),
+    "vg_conv2d_stem_wgrad_partial_h": (c_int, [_G, _P, _P, _P, c_size_t, _P]),
     "vg_cast_f32_to_bf16": (c_int, [_P, _P, c_size_t, _P]),
     "vg_cast_bf16_to_f32": (c_int, [_P, _P, c_size_t, _P]),
     "vg_add_h": (c_int, [_P, _P, _P, c_size_t, _P]),

@@ -598,6 +598,11 @@ def _conv_with_stats(mode, g, args, out, src=None):
     return True
 
 
+def _stem_h(mode, g):
+    """Whether contraction `mode` of an image-side layer (f32 image, bf16 feature map) has a kernel of its own."""
+    return _mode == "bf16" and bool(_hip.load().vg_conv2d_stem_h_applies(mode, ctypes.byref(g.c)))
+
+
 def _h_contraction(mode, g, a, b, out_dtype):
     """Whether contraction `mode` runs on bf16 tensors: bf16 storage mode, a result stored as bf16 (weight gradients are
     f32 always) and a geometry the bf16 kernels serve. Operands that arrive as f32 are converted first."""
@@ -618,6 +623,11 @@ def raw_conv_fwd(g, x, w, bias, out_dtype=None):
         wh = plane_cache.bf16_copy(w) if w.dtype == F32 else w
         y = _new_act(g.N, g.Co, g.Ho, g.Wo, x, g.flat, BF16)
         _launch_conv(0, g, lambda: call("vg_conv2d_fwd_h", ctypes.byref(g.c), _p(xh), _p(wh), _ptr(bias), _p(y), _stream()))
+        return y
+    if out_dtype == BF16 and x.dtype == F32 and _stem_h(0, g):      # image stem: f32 image in, bf16 feature map out
+        y = _new_act(g.N, g.Co, g.Ho, g.Wo, x, g.flat, BF16)
+        _launch_conv(0, g, lambda: call("vg_conv2d_stem_fwd_h", ctypes.byref(g.c), _ptr(x), _ptr(w), _ptr(bias), _p(y),
+                                        _hip.ACT_NONE, c_float(0.0), _stream()))
         return y
     x, w = _f32(x), _f32(w)
     y = _new_act(g.N, g.Co, g.Ho, g.Wo, x, g.flat)
@@ -653,6 +663,11 @@ def raw_conv_dgrad(g, gy, w, bias, out_dtype=None):
         wh = plane_cache.bf16_copy(w) if w.dtype == F32 else w
         gx = _new_act(g.N, g.Ci, g.H, g.W, gy, g.flat, BF16)
         _launch_conv(1, g, lambda: call("vg_conv2d_dgrad_h", ctypes.byref(g.c), _p(gh), _p(wh), _ptr(bias), _p(gx), _stream()))
+        return gx
+    if out_dtype == F32 and gy.dtype == BF16 and _stem_h(1, g):     # bf16 feature-map gradient in, f32 image gradient out
+        gx = _new_act(g.N, g.Ci, g.H, g.W, gy, g.flat)
+        _launch_conv(1, g, lambda: call("vg_conv2d_stem_dgrad_h", ctypes.byref(g.c), _p(gy), _ptr(w), _ptr(bias), _ptr(gx),
+                                        _stream()))
         return gx
     gy, w = _f32(gy), _f32(w)
     gx = _new_act(g.N, g.Ci, g.H, g.W, gy, g.flat)
@@ -694,6 +709,13 @@ def raw_conv_wgrad(g, gy, x, w_shape):
                                         c_size_t(nbytes), _stream()))
         if nbytes:
             call("vg_conv2d_wgrad_reduce", ctypes.byref(g.c), _ptr(gw), wsp, _stream())
+        return gw
+    if gy.dtype == BF16 and x.dtype == F32 and _stem_h(2, g):
+        nbytes = _hip.load().vg_conv2d_wgrad_workspace_bytes(ctypes.byref(g.c))
+        wsp = ctypes.c_void_p(workspace(nbytes, x.device).data_ptr())
+        _launch_conv(2, g, lambda: call("vg_conv2d_stem_wgrad_partial_h", ctypes.byref(g.c), _p(gy), _ptr(x), wsp,
+                                        c_size_t(nbytes), _stream()))
+        call("vg_conv2d_wgrad_reduce", ctypes.byref(g.c), _ptr(gw), wsp, _stream())
         return gw
     gy, x = _f32(gy), _f32(x)
     nbytes, wsp = _conv_workspace(2, g, x.device)
@@ -787,10 +809,15 @@ class ConvActFn(Function):
         if wm.numel() != g.w_numel():
             raise _hip.HipError("weight has %d elements, geometry expects %d" % (wm.numel(), g.w_numel()))
         xm = _f32(xm)
-        y = _new_act(g.N, g.Co, g.Ho, g.Wo, xm, g.flat)
-        _launch_conv(0, g, lambda: call("vg_conv2d_fwd_act", ctypes.byref(g.c), _ptr(xm), _ptr(wm), _ptr(bias), _ptr(y),
-                                        act, c_float(slope), _stream()))
-        y = _cast_raw(y, _feature_dtype(g.Co))
+        if _feature_dtype(g.Co) == BF16 and _stem_h(0, g):
+            y = _new_act(g.N, g.Co, g.Ho, g.Wo, xm, g.flat, BF16)
+            _launch_conv(0, g, lambda: call("vg_conv2d_stem_fwd_h", ctypes.byref(g.c), _ptr(xm), _ptr(wm), _ptr(bias),
+                                            _p(y), act, c_float(slope), _stream()))
+        else:
+            y = _new_act(g.N, g.Co, g.Ho, g.Wo, xm, g.flat)
+            _launch_conv(0, g, lambda: call("vg_conv2d_fwd_act", ctypes.byref(g.c), _ptr(xm), _ptr(wm), _ptr(bias),
+                                            _ptr(y), act, c_float(slope), _stream()))
+            y = _cast_raw(y, _feature_dtype(g.Co))
         ctx.g, ctx.act, ctx.slope = g, act, slope
         ctx.label = grads.ticket()
         ctx.norm_src = norm_bwd.source_of(x)

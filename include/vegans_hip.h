@@ -382,6 +382,18 @@ int vg_conv2d_fwd_h(const vg_conv_geom* g, const void* x, const void* w, const f
 int vg_conv2d_dgrad_h(const vg_conv_geom* g, const void* gy, const void* w, const float* bias, void* gx, void* stream);
 int vg_conv2d_wgrad_partial_h(const vg_conv_geom* g, const void* gy, const void* x, float* gw, void* workspace,
                               size_t workspace_bytes, void* stream);
+/* The layers next to an image in such a network (reference: the first nn.Conv2d of a critic and the last
+ * nn.ConvTranspose2d of a generator, e.g. examples/example_input_formats.py:64-77) have an f32 image on one side and a
+ * bf16 feature map on the other: forward f32 x -> bf16 y with an optional ReLU / LeakyReLU, input gradient bf16 gy ->
+ * f32 gx, weight gradient from bf16 gy and f32 x into the split-K slabs of vg_conv2d_wgrad_workspace_bytes (added by
+ * vg_conv2d_wgrad_reduce). vg_conv2d_stem_h_applies(mode, g): whether the stem / scatter kernels serve (mode, g). */
+int vg_conv2d_stem_h_applies(int mode, const vg_conv_geom* g);
+int vg_conv2d_stem_fwd_h(const vg_conv_geom* g, const float* x, const float* w, const float* bias, void* y, int act,
+                         float slope, void* stream);
+int vg_conv2d_stem_dgrad_h(const vg_conv_geom* g, const void* gy, const float* w, const float* bias, float* gx,
+                           void* stream);
+int vg_conv2d_stem_wgrad_partial_h(const vg_conv_geom* g, const void* gy, const float* x, void* workspace,
+                                   size_t workspace_bytes, void* stream);
 int vg_cast_f32_to_bf16(const float* in, void* out, size_t n, void* stream);
 int vg_cast_bf16_to_f32(const void* in, float* out, size_t n, void* stream);
 int vg_add_h(const void* a, const void* b, void* out, size_t n, void* stream);

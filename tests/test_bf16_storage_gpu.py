@@ -286,3 +286,65 @@ def test_gradient_penalty_through_a_bf16_critic(gpu, bf16_mode):
         # gradient, a sum of many rounded terms of both signs, can be off by more than the tensor as a whole)
         d = (a.grad.detach().cpu().double() - b.grad.double()).norm() / b.grad.double().norm()
         assert float(d) <= 5e-2, (name, float(d))
+
+
+STEM_CASES = [
+    # N, Ci, H, W, Co, k, s, p
+    (8, 3, 64, 64, 64, 4, 2, 1),      # DCGAN image stem / generator tail
+    (3, 1, 12, 12, 64, 5, 2, 2),      # one channel, 5x5 stride 2, ragged tiles
+    (6, 3, 11, 9, 128, 3, 1, 1),      # 3x3 stride 1, two channel tiles
+]
+
+
+@pytest.mark.parametrize("case", STEM_CASES)
+def test_stem_h_kernels_equal_the_f32_kernels_on_the_same_values(gpu, case):
+    """The image-side layers of a bf16 network (f32 image, bf16 feature map) run the f32 stem / scatter kernels with the
+    feature-map side loaded or stored as bf16: bit-identical to the f32 entry points on the widened values (forward:
+    rounded once at the store)."""
+    from vegans import _hip
+    from vegans.engine import ops
+    N, Ci, H, W, Co, k, s, p = case
+    lib = _hip.load()
+    CL = torch.channels_last
+    gen = torch.Generator().manual_seed(sum(case))
+    geo = ops.Geom(N, H, W, Ci, Co, k, k, s, s, p, p)
+    x = torch.randn(N, Ci, H, W, generator=gen).to(gpu).contiguous(memory_format=CL)
+    w = (torch.randn(Co, Ci, k, k, generator=gen) * 0.1).to(gpu).contiguous(memory_format=CL)
+    b = torch.randn(Co, generator=gen).to(gpu)
+    gy_h = torch.randn(N, Co, geo.Ho, geo.Wo, generator=gen).bfloat16().to(gpu).contiguous(memory_format=CL)
+    gy_f = gy_h.float()
+    st = _hip._stream()
+    P = lambda t: None if t is None else ctypes.c_void_p(t.data_ptr())
+    G = ctypes.byref(geo.c)
+    for mode in (0, 1):
+        assert lib.vg_conv2d_stem_h_applies(mode, G), mode
+    # (a weight gradient small enough for a single split-K slab stays on the generic kernel)
+    assert lib.vg_conv2d_stem_h_applies(2, G) == (1 if lib.vg_conv2d_wgrad_workspace_bytes(G) > 0 else 0)
+    assert case != STEM_CASES[0] or lib.vg_conv2d_stem_h_applies(2, G)
+    # forward, with and without the fused activation
+    for act, slope in ((0, 0.0), (2, 0.2)):
+        y_h = torch.empty((N, Co, geo.Ho, geo.Wo), dtype=torch.bfloat16, device=gpu, memory_format=CL)
+        y_f = torch.empty((N, Co, geo.Ho, geo.Wo), dtype=torch.float32, device=gpu, memory_format=CL)
+        _hip.call("vg_conv2d_stem_fwd_h", G, P(x), P(w), P(b), P(y_h), act, ctypes.c_float(slope), st)
+        if act:
+            _hip.call("vg_conv2d_fwd_act", G, P(x), P(w), P(b), P(y_f), act, ctypes.c_float(slope), st)
+        else:
+            _hip.call("vg_conv2d_fwd", G, P(x), P(w), P(b), P(y_f), st)
+        assert torch.equal(y_h, y_f.bfloat16()), "stem forward, act %d" % act
+    # input gradient
+    gx_h = torch.empty((N, Ci, H, W), dtype=torch.float32, device=gpu, memory_format=CL)
+    gx_f = torch.empty_like(gx_h)
+    _hip.call("vg_conv2d_stem_dgrad_h", G, P(gy_h), P(w), None, P(gx_h), st)
+    _hip.call("vg_conv2d_dgrad", G, P(gy_f), P(w), None, P(gx_f), st)
+    assert torch.equal(gx_h, gx_f), "stem input gradient"
+    # weight gradient
+    if not lib.vg_conv2d_stem_h_applies(2, G):
+        return
+    nbytes = lib.vg_conv2d_wgrad_workspace_bytes(G)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=gpu)
+    gw_h = torch.empty((Co, Ci, k, k), dtype=torch.float32, device=gpu, memory_format=CL)
+    gw_f = torch.empty_like(gw_h)
+    _hip.call("vg_conv2d_stem_wgrad_partial_h", G, P(gy_h), P(x), P(ws), ctypes.c_size_t(nbytes), st)
+    _hip.call("vg_conv2d_wgrad_reduce", G, P(gw_h), P(ws), st)
+    _hip.call("vg_conv2d_wgrad", G, P(gy_f), P(x), P(gw_f), P(ws), ctypes.c_size_t(nbytes), st)
+    assert torch.equal(gw_h, gw_f), "stem weight gradient"
