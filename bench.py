@@ -98,8 +98,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--dtype", choices=["fp32", "fp32_split", "bf16"], default="fp32",
-                    help="multiplier precision of the convolutions in the timed region (fp32 is the parity-checked mode)")
+    ap.add_argument("--dtype", choices=["fp32", "fp32_split", "bf16", "bf16_compute"], default="fp32",
+                    help="precision mode of the timed region (fp32 is the parity-checked mode; bf16 = feature maps stored "
+                         "as bf16; bf16_compute = f32 tensors, bf16 matrix operands)")
     ap.add_argument("--no-bf16-extra", action="store_true", help="skip the extra bf16-mode and split-mode measurements of an fp32 run")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
@@ -196,13 +197,18 @@ def main():
     # the changed precision makes train_on_batch record new graphs), reported beside the fp32 figure, never as `value`.
     # Likewise the split mode, which computes f32-grade products on the bf16 matrix cores.
     extras = {}
-    notes = {"bf16": "convolutions with bf16 matrix-core operands and f32 accumulation; everything else f32; "
-                     "losses within 2e-2 of the fp32 reference (tests/test_models_gpu.py)",
+    notes = {"bf16": "bf16 data path: feature maps and their gradients stored as bf16 in HBM and fed to the bf16 matrix "
+                     "cores as they lie in memory, f32 accumulation; parameters, their gradients, optimizer state, "
+                     "BatchNorm statistics, losses, images and scores f32; losses within 5e-2 of the fp32 reference "
+                     "(tests/test_models_gpu.py, tests/test_bf16_storage_gpu.py)",
+             "bf16_compute": "f32 tensors in HBM; operands of the convolutions rounded to bf16 ahead of the matrix "
+                             "cores, f32 accumulation; everything else f32; losses within 2e-2 of the fp32 reference "
+                             "(tests/test_models_gpu.py)",
              "fp32_split": "convolution operands split exactly into three bf16 terms, six bf16 MFMA products per f32 "
                            "product, f32 accumulation; error against float64 no larger than the f32 MFMA kernels' "
                            "(tests/test_ops_gpu.py) and the fp32 parity tolerances hold (tests/test_models_gpu.py)"}
     if args.dtype == "fp32" and not args.no_bf16_extra and world == 1:     # extras on the single-GPU line only
-        for mode in ("bf16", "fp32_split"):
+        for mode in ("bf16", "bf16_compute", "fp32_split"):
             ops.set_matmul_precision(mode)
             for i in range(SETUP_STEPS + args.warmup):
                 step(i)
@@ -232,12 +238,15 @@ def main():
                 shape, (n, ms, fl) = max(bt.summary().items(), key=lambda kv: kv[1][1])
                 tf = fl / (ms * 1e-3) / 1e12
                 extras["bf16_mode"]["roofline"] = {
-                    "bound": "mfma", "kernel": "pgemm_kernel (bf16 plane GEMM) on the launches the f32 path serves with " + shape,
+                    "bound": "mfma", "kernel": "pgemm_kernel<..., OUT_H> (bf16 implicit GEMM on bf16 tensors) on the launches "
+                                               "the f32 path serves with " + shape,
                     "achieved": round(tf, 1), "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(tf / BF16_MFMA_PEAK_TFLOPS, 4), "launches": n, "avg_launch_us": round(1e3 * ms / n, 2),
                     "traffic": None,
-                    "note": "tensors stay f32 in HBM in this mode (operands are rounded to bf16 planes ahead of the "
-                            "contraction), so it is bound by operand traffic, not by the matrix cores"}
+                    "note": "operands are read as bf16 from HBM / L2 as they lie in memory; at 340 flop per HBM byte these "
+                            "layers sit at the ridge of the bf16 roofline, and the implicit GEMM re-reads each "
+                            "activation kh*kw/s^2 times through L2: bound by operand traffic into the CUs, not by the "
+                            "matrix cores"}
 
     # Per-kernel durations for the roofline entry. Kernels inside a replayed graph cannot be timed one by one, so
     # the same iterations run again eagerly with a start/stop event pair attached to every convolution launch, on the
@@ -273,7 +282,7 @@ def main():
             "metric": "training images/sec (G+D step) DCGAN-64 WGAN-GP",
             "value": round(value, 2), "unit": "images/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": {"fp32": "f32", "bf16": "bf16", "fp32_split": "f32 (3xbf16 split)"}[args.dtype], "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None, "dtype": {"fp32": "f32", "bf16": "bf16", "bf16_compute": "bf16 operands, f32 tensors", "fp32_split": "f32 (3xbf16 split)"}[args.dtype], "data": "synthetic",
             "config": {"workload": "WassersteinGANGP DCGAN-64 (ngf=ndf=64, BatchNorm critic), 3x64x64, z=100, "
                                    "batch 256 per GPU, %s, steps G1:D1, RMSprop" % args.dtype,
                        "global_batch": global_batch, "parallelism": "dp%d" % world if world > 1 else "single"},
