@@ -409,14 +409,20 @@ class _PlaneCache:
         """bf16 copy of f32 tensor `t` in its memory order (a weight on its way into the bf16 contractions); kept for
         the rest of the iteration like the planes above."""
         key = (t.data_ptr(), "h")
+        cur = torch.cuda.current_stream(t.device)
         if self.active:
             hit = self.entries.get(key)
             if hit is not None and hit[0]._version == hit[1] and hit[0].numel() == t.numel():
+                # made by a pass that runs on another stream (engine/streams.py): order this stream behind the conversion
+                if hit[3] != cur:
+                    cur.wait_event(hit[4])
                 return hit[2]
         copy = torch.empty(t.numel(), dtype=BF16, device=t.device)
         call("vg_cast_f32_to_bf16", _ptr(t), _p(copy), c_size_t(t.numel()), _stream())
         if self.active:
-            self.entries[key] = (t, t._version, copy)
+            done = torch.cuda.Event()
+            done.record(cur)
+            self.entries[key] = (t, t._version, copy, cur, done)
         return copy
 
 

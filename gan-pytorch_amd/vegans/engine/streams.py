@@ -38,8 +38,9 @@ def enabled():
     if os.environ.get("VEGANS_HIP_STREAMS", "1") == "0":
         return False
     from . import ops
-    # the operand-plane cache of the bf16 / split modes is shared by all passes of an iteration: one stream there
-    return ops.matmul_precision() == "fp32"
+    # the operand-plane cache of the bf16_compute / split modes is shared by all passes of an iteration: one stream
+    # there. In the bf16 data path only the bf16 copies of the weights are shared, and those carry an event.
+    return ops.matmul_precision() in ("fp32", "bf16")
 
 
 def set_enabled(flag):

@@ -142,6 +142,40 @@ def test_replayed_step_matches_eager_in_split_mode(gpu):
             _same(s0[k].float(), s1[k].float(), True, k)
 
 
+@pytest.mark.parametrize("algo,steps,extra", [("WassersteinGANGP", None, {}), ("LSGAN", {"Generator": 2}, {})])
+def test_replayed_step_matches_eager_in_the_bf16_data_path(gpu, algo, steps, extra):
+    """The bf16 data path (bf16 feature maps, the critic's passes of a sub-step on separate streams sharing the bf16
+    copies of the weights): replayed and eager iterations agree bit for bit, the first run of the pair included, as in
+    f32. Width 32 puts the inner layers on the bf16 contractions."""
+    import bench_configs as cfg
+    from vegans.engine import ops
+    iters, B = 6, 8
+    data = cfg.synthetic_images(B * iters, (3, 16, 16), seed=8)
+    g = torch.Generator().manual_seed(12)
+    zs = [torch.randn(B, 16, 1, 1, generator=g) for _ in range(iters)]
+    previous = ops.set_matmul_precision("bf16")
+    try:
+        results = []
+        for use_graph in (False, True, False):
+            m = _model(algo, steps, width=32, **extra)
+            batches = [m._to_device(data[i * B:(i + 1) * B]) for i in range(iters)]
+            losses, next_draw, entries = _run(m, batches, [z.to("cuda") for z in zs], use_graph)
+            if use_graph:
+                assert len(entries) == 1 and entries[0].graph is not None and not entries[0].failed
+            results.append((losses, _state(m)))
+            assert not ops.plane_cache.active and not ops.plane_cache.entries
+    finally:
+        ops.set_matmul_precision(previous)
+    for other in (1, 2):
+        (l0, s0), (l1, s1) = results[0], results[other]
+        for i, (a, b) in enumerate(zip(l0, l1)):
+            for k in a:
+                _same(a[k].reshape(1), b[k].reshape(1), True, "run %d iteration %d loss %s" % (other, i, k))
+        for k in s0:
+            if isinstance(s0[k], torch.Tensor):
+                _same(s0[k].float(), s1[k].float(), True, "run %d %s" % (other, k))
+
+
 def test_graph_follows_hyperparameter_and_shape_changes(gpu):
     """Values frozen into a graph are part of its signature: a new learning rate or batch shape takes a new graph
     (after its own eager calls) instead of replaying stale constants."""
