@@ -30,6 +30,13 @@ struct PgemmParams {
 
 static __device__ __attribute__((aligned(16))) unsigned int vg_zero_page_u[4] = {0u, 0u, 0u, 0u};  // never written
 
+// Diagnostic builds only (tools/micro/pgemm_ablate.py compiles the library with -DPG_ABLATE=<bits> to see where the time
+// of the loop goes; results are then wrong by construction): 1 no global loads, 2 no LDS stores, 4 no fragment reads,
+// 8 no MFMAs, 16 no result stores.
+#ifndef PG_ABLATE
+#define PG_ABLATE 0
+#endif
+
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 
 // OUT_H: the result leaves as bf16 (round to nearest even) instead of f32 - the convolution of a network whose
@@ -203,8 +210,12 @@ __global__ void __launch_bounds__(NW * 64) pgemm_kernel(const PgemmParams pp) {
   auto ld_planes = [&](const __bf16* base, long long pstride, size_t off, bool ok, u32x4 (&dst)[NP]) {
 #pragma unroll
     for (int q = 0; q < NP; ++q) {
-      const void* ptr = ok ? (const void*)(base + (size_t)q * pstride + off) : (const void*)vg_zero_page_u;
-      dst[q] = *reinterpret_cast<const u32x4*>(ptr);
+      if constexpr ((PG_ABLATE & 1) != 0) {
+        dst[q] = u32x4{(unsigned)off, 0u, 0u, 0u};
+      } else {
+        const void* ptr = ok ? (const void*)(base + (size_t)q * pstride + off) : (const void*)vg_zero_page_u;
+        dst[q] = *reinterpret_cast<const u32x4*>(ptr);
+      }
     }
   };
 
@@ -294,6 +305,13 @@ __global__ void __launch_bounds__(NW * 64) pgemm_kernel(const PgemmParams pp) {
   };
 
   auto store_tiles = [&](int buf) {   // tile in stage `buf` -> LDS buffer `buf`
+    if constexpr ((PG_ABLATE & 2) != 0) {
+#pragma unroll
+      for (int i = 0; i < UA; ++i) asm volatile("" ::"v"(ra[buf][i][0]));
+#pragma unroll
+      for (int i = 0; i < UB; ++i) asm volatile("" ::"v"(rb[buf][i][0]));
+      return;
+    }
     __bf16* As = smem + buf * BUF;
     __bf16* Bs = As + A_ALL;
 #pragma unroll
@@ -352,6 +370,7 @@ __global__ void __launch_bounds__(NW * 64) pgemm_kernel(const PgemmParams pp) {
 
   // fragment q * T + i is plane q of 32-row tile i
   auto load_frags = [&](int buf, int s, bf16x8 (&af)[NP * TM], bf16x8 (&bf)[NP * TN]) {
+    if constexpr ((PG_ABLATE & 4) != 0) return;
     const __bf16* As = smem + buf * BUF;
     const __bf16* Bs = As + A_ALL;
 #pragma unroll
@@ -376,6 +395,13 @@ __global__ void __launch_bounds__(NW * 64) pgemm_kernel(const PgemmParams pp) {
   };
   // every plane pair (qa, qb) with qa + qb < NP, smallest terms first
   auto mma_frags = [&](const bf16x8 (&af)[NP * TM], const bf16x8 (&bf)[NP * TN]) {
+    if constexpr ((PG_ABLATE & 8) != 0) {
+#pragma unroll
+      for (int i = 0; i < NP * TM; ++i) asm volatile("" ::"v"(af[i]));
+#pragma unroll
+      for (int i = 0; i < NP * TN; ++i) asm volatile("" ::"v"(bf[i]));
+      return;
+    }
 #pragma unroll
     for (int order = NP - 1; order >= 0; --order)
 #pragma unroll
@@ -389,6 +415,12 @@ __global__ void __launch_bounds__(NW * 64) pgemm_kernel(const PgemmParams pp) {
   };
 
   bf16x8 afx[NP * TM], bfx[NP * TN], afy[NP * TM], bfy[NP * TN];
+  if constexpr ((PG_ABLATE & 4) != 0) {
+#pragma unroll
+    for (int i = 0; i < NP * TM; ++i) afx[i] = afy[i] = __builtin_bit_cast(bf16x8, u32x4{(unsigned)tid, 1u, 2u, 3u});
+#pragma unroll
+    for (int i = 0; i < NP * TN; ++i) bfx[i] = bfy[i] = __builtin_bit_cast(bf16x8, u32x4{(unsigned)tid, 1u, 2u, 3u});
+  }
 
   // One k-step on buffer `buf` (NS 16-deep slices). On entry afx/bfx hold slice 0 and the other register stage holds
   // tile kt+1 (loads issued two k-steps ago); it is written to the other buffer under the MFMAs, the loads of tile
@@ -437,6 +469,17 @@ __global__ void __launch_bounds__(NW * 64) pgemm_kernel(const PgemmParams pp) {
   if (kt < nk) k_step(kt, 0, false);
 
   // ---- epilogue: lane holds column (lane&31) and rows (e&3)+8*(e>>2)+4*(lane>>5) of each 32x32 tile ----
+  if constexpr ((PG_ABLATE & 16) != 0) {
+    float keep = 0.f;
+#pragma unroll
+    for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < TN; ++ni)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) keep += acc[mi][ni][e];
+    if (keep == 123.456f) p.out[0] = keep;      // (practically never: keeps the accumulators alive)
+    return;
+  }
   float* outp = p.out;
   if constexpr (MODE == MODE_WGRAD) outp += (size_t)zz * p.slab_stride;
   // Per column tile: validity and the bias value, fetched once and pinned here. A load whose first use sits inside the

@@ -709,12 +709,12 @@ def raw_conv_wgrad(g, gy, x, w_shape):
         raise _hip.HipError("weight gradient shape %s does not match the geometry" % (tuple(w_shape),))
     if _h_contraction(2, g, gy, x, F32) and (gy.dtype == BF16 or x.dtype == BF16):
         gh, xh = _cast_raw(gy, BF16), _cast_raw(x, BF16)
-        nbytes = _hip.load().vg_conv2d_wgrad_workspace_bytes(ctypes.byref(g.c))
+        nbytes = _hip.load().vg_conv2d_wgrad_h_workspace_bytes(ctypes.byref(g.c))
         wsp = ctypes.c_void_p(workspace(nbytes, x.device).data_ptr()) if nbytes else None
         _launch_conv(2, g, lambda: call("vg_conv2d_wgrad_partial_h", ctypes.byref(g.c), _p(gh), _p(xh), _ptr(gw), wsp,
                                         c_size_t(nbytes), _stream()))
         if nbytes:
-            call("vg_conv2d_wgrad_reduce", ctypes.byref(g.c), _ptr(gw), wsp, _stream())
+            call("vg_conv2d_wgrad_reduce_h", ctypes.byref(g.c), _ptr(gw), wsp, _stream())
         return gw
     if gy.dtype == BF16 and x.dtype == F32 and _stem_h(2, g):
         nbytes = _hip.load().vg_conv2d_wgrad_workspace_bytes(ctypes.byref(g.c))

@@ -376,12 +376,15 @@ int vg_clamp(float* param, size_t n, float lo, float hi, void* stream);
  * vg_conv2d_h_applies(mode, g) tells whether contraction `mode` (0 fwd, 1 dgrad, 2 wgrad) of geometry g runs on bf16
  * tensors (channel counts in multiples of 8, more than 32 GEMM columns, not one of the thin / stem / 1x1 special
  * kernels); other shapes go through the f32 entry points on converted copies. No workspace except the split-K slabs
- * of the weight gradient (vg_conv2d_wgrad_workspace_bytes; vg_conv2d_wgrad_reduce adds them as for f32). */
+ * of the weight gradient (vg_conv2d_wgrad_h_workspace_bytes, fewer and longer splits than the f32 plan;
+ * vg_conv2d_wgrad_reduce_h adds them in split order). */
 int vg_conv2d_h_applies(int mode, const vg_conv_geom* g);
 int vg_conv2d_fwd_h(const vg_conv_geom* g, const void* x, const void* w, const float* bias, void* y, void* stream);
 int vg_conv2d_dgrad_h(const vg_conv_geom* g, const void* gy, const void* w, const float* bias, void* gx, void* stream);
+size_t vg_conv2d_wgrad_h_workspace_bytes(const vg_conv_geom* g);
 int vg_conv2d_wgrad_partial_h(const vg_conv_geom* g, const void* gy, const void* x, float* gw, void* workspace,
                               size_t workspace_bytes, void* stream);
+int vg_conv2d_wgrad_reduce_h(const vg_conv_geom* g, float* gw, const void* workspace, void* stream);
 /* The layers next to an image in such a network (reference: the first nn.Conv2d of a critic and the last
  * nn.ConvTranspose2d of a generator, e.g. examples/example_input_formats.py:64-77) have an f32 image on one side and a
  * bf16 feature map on the other: forward f32 x -> bf16 y with an optional ReLU / LeakyReLU, input gradient bf16 gy ->

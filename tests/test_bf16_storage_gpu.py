@@ -104,10 +104,10 @@ def test_h_contractions_against_f32_on_the_same_bf16_values(gpu, case):
         assert _rel_elem_err(gx.float(), xr.grad, 2e-3) <= BF16_STORE, "input gradient"
     if 2 in modes:
         gw = torch.empty((Co, Ci, k, k), dtype=torch.float32, device=gpu, memory_format=CL)
-        nbytes = lib.vg_conv2d_wgrad_workspace_bytes(ctypes.byref(geo.c))
+        nbytes = lib.vg_conv2d_wgrad_h_workspace_bytes(ctypes.byref(geo.c))
         ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=gpu)
         _hip.call("vg_conv2d_wgrad_partial_h", ctypes.byref(geo.c), P(gd), P(xd), P(gw), P(ws), ctypes.c_size_t(nbytes), st)
-        _hip.call("vg_conv2d_wgrad_reduce", ctypes.byref(geo.c), P(gw), P(ws), st)
+        _hip.call("vg_conv2d_wgrad_reduce_h", ctypes.byref(geo.c), P(gw), P(ws), st)
         assert _scale_err(gw, wr.grad) <= 2e-5, "weight gradient (f32 result of exact bf16 products)"
 
 
