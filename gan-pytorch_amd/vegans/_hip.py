@@ -196,24 +196,6 @@ def _ptr(t):
     return c_void_p(t.data_ptr())
 
 
-def _hptr(t):
-    """Device pointer of a dense bfloat16 GPU tensor (None -> null): the activations of the bf16 storage mode."""
-    if t is None:
-        return None
-    if not t.is_cuda:
-        raise HipError("tensor is not on the GPU: this engine only runs on MI355X (device='cuda')")
-    if t.dtype != torch.bfloat16:
-        raise HipError("tensor dtype %s where a bfloat16 activation is expected" % t.dtype)
-    return c_void_p(t.data_ptr())
-
-
-def _aptr(t, like):
-    """Pointer of activation `t`, which must have the storage type of `like` (kernels take one type per call)."""
-    if t is None:
-        return None
-    return _hptr(t) if like.dtype == torch.bfloat16 else _ptr(t)
-
-
 def _dense(t):
     """True if the tensor's memory is one gap-free block (any permutation of a contiguous layout)."""
     return t.is_contiguous() or t.is_contiguous(memory_format=torch.channels_last) or t.numel() <= 1 or \

@@ -1354,6 +1354,7 @@ class MeanLossFn(Function):
 
     @staticmethod
     def forward(ctx, pred, sign):
+        ctx.stored = pred.dtype
         pred = _flat_dense(pred)
         n = pred.numel()
         out = torch.empty((), dtype=torch.float32, device=pred.device)
@@ -1370,7 +1371,7 @@ class MeanLossFn(Function):
         pred = ctx.like
         d = torch.empty_like(pred)
         call("vg_loss_mean_bwd", _ptr(gout), c_size_t(pred.numel()), c_float(ctx.sign), _ptr(d), _stream())
-        return d, None
+        return _cast_raw(d, ctx.stored), None
 
 
 class PointLossFn(Function):
@@ -1378,6 +1379,7 @@ class PointLossFn(Function):
 
     @staticmethod
     def forward(ctx, pred, target, tconst, kind):
+        ctx.stored = pred.dtype
         pred = _flat_dense(pred)
         if target is not None:
             target = _match_layout(_flat_dense(target), pred)
@@ -1397,12 +1399,13 @@ class PointLossFn(Function):
         d = torch.empty_like(pred)
         call("vg_loss_%s_bwd" % ctx.kind, _ptr(gout), _ptr(pred), _ptr(target), c_float(ctx.tconst),
              c_size_t(pred.numel()), _ptr(d), _stream())
-        return d, None, None, None
+        return _cast_raw(d, ctx.stored), None, None, None
 
 
 class L1LossFn(Function):
     @staticmethod
     def forward(ctx, a, b):
+        ctx.stored = (a.dtype, b.dtype)
         a = _flat_dense(a)
         b = _match_layout(_flat_dense(b), a)
         if a.shape != b.shape:
@@ -1424,7 +1427,7 @@ class L1LossFn(Function):
         if da is None and db is None:
             return None, None
         call("vg_loss_l1_bwd", _ptr(gout), _ptr(a), _ptr(b), c_size_t(a.numel()), _ptr(da), _ptr(db), _stream())
-        return da, db
+        return _cast_raw(da, ctx.stored[0]), _cast_raw(db, ctx.stored[1])
 
 
 class CombineFn(Function):

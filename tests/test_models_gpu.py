@@ -559,6 +559,73 @@ def _float64_losses(oracle, who, X, Z, alpha):
     return {k: float(v.detach()) for k, v in out.items()}
 
 
+@pytest.mark.parametrize("mode", ["bf16", "bf16_compute"])
+def test_bf16_data_path_teacher_forced_full_width_dcgan64(gpu, capsys, mode):
+    """The bf16 data path at the north-star layer sizes (WGAN-GP, DCGAN-64 with ngf = ndf = 64 on 3x64x64, z = 100,
+    RMSprop, batch 64), teacher-forced against the fp32 oracle for 8 iterations: before every sub-step the engine takes
+    over the oracle's parameters, buffers and optimizer state, and both run the sub-step on the same X, Z and alpha.
+    Stated tolerance: every loss within the mode's loss tolerance of its own value (floor 0.1; the critic's total at that
+    share of its largest term); every parameter tensor's gradient, in the l2 norm, within 8e-2 of the oracle's for the
+    critic and 2.5e-1 for the generator. Measured: critic 1-4e-2, generator 7e-2 (last layer) to 1.7e-1 (first layer: its
+    gradient has come down through the whole critic and the whole generator, and every BatchNorm on the way subtracts
+    two projections of it, which amplifies relative error). The same numbers in the "bf16_compute" mode (f32 tensors,
+    bf16 matrix operands) are 1-4e-2 and 6e-2 to 1.5e-1: it is the 8-bit products that set these, storing the feature
+    maps as bf16 adds a tenth on top. The worst values measured are printed."""
+    import bench_configs as cfg
+    from vegans.engine import ops
+    iters, B = 8, 64
+
+    def nets():
+        return (cfg.dcgan_init(cfg.dcgan_generator(100, 64, 3, 64), 1), cfg.dcgan_init(cfg.dcgan_critic(64, 3, 64), 2))
+
+    okw = {"Generator": {"lr": 1e-4}, "Adversariat": {"lr": 5e-5}}
+    previous = ops.set_matmul_precision(mode)
+    try:
+        oracle, model = _oracle_and_model("wgangp", "WassersteinGANGP", nets, (3, 64, 64), (100, 1, 1), okw)
+        pool = [cfg.synthetic_images(B, (3, 64, 64), seed=40 + i) for i in range(4)]
+        zgen = torch.Generator().manual_seed(10)
+        oracle._set_mode(True)
+        model.use_step_graph = False
+        model._create_steps(None)
+        model.train()
+        worst_loss, worst_grad = {}, {}
+        for it in range(iters):
+            X = torch.from_numpy(pool[it % len(pool)])
+            Xd = model._to_device(pool[it % len(pool)])
+            Z = torch.randn(B, 100, 1, 1, generator=zgen)
+            A = np.random.default_rng(1000 + it).random((B, 1, 1, 1))
+            model._draw_alpha = lambda n, A=A: torch.from_numpy(A.astype(np.float32)).to("cuda")
+            for who in ("Generator", "Adversariat"):
+                _sync_from_oracle(oracle, model)
+                want = oracle.sub_step(who, X, Z.clone(), None, A if who == "Adversariat" else None)
+                got = _engine_sub_step(model, who, Xd, Z.to("cuda"))
+                for k, v in want.items():
+                    if k == "RealFakeRatio":
+                        continue
+                    scale = max(abs(v), 1e-1)
+                    if k == "Adversariat":
+                        scale = max(scale, 0.5 * abs(want["Adversariat_fake"]), 0.5 * abs(want["Adversariat_real"]),
+                                    10 * abs(want["Adversariat_grad"]))
+                    worst_loss[k] = max(worst_loss.get(k, 0.0), abs(float(got[k]) - v) / scale)
+                for (k, po), pm in zip(oracle.nets[who].named_parameters(), model.neural_nets[who].network.parameters()):
+                    if po.grad is None or float(po.grad.norm()) == 0.0:
+                        continue
+                    assert pm.grad is not None and pm.grad.dtype == torch.float32, k
+                    err = float((pm.grad.detach().cpu().double() - po.grad.double()).norm() / po.grad.double().norm())
+                    worst_grad[who + "." + k] = max(worst_grad.get(who + "." + k, 0.0), err)
+    finally:
+        ops.set_matmul_precision(previous)
+    with capsys.disabled():
+        print("\n%s mode, full-width DCGAN-64, %d teacher-forced iterations: worst loss distance %s; worst gradient "
+              "distance (l2) %s" % (mode, iters, {k: "%.1e" % v for k, v in worst_loss.items()},
+                                    {k: "%.1e" % v for k, v in worst_grad.items()}))
+    for k, v in worst_loss.items():
+        assert v <= BF16_LOSS_TOL["bf16"], "loss %s: %.2e of its value from the fp32 oracle" % (k, v)
+    for k, v in worst_grad.items():
+        bound = 2.5e-1 if k.startswith("Generator") else 8e-2
+        assert v <= bound, "gradient of %s: %.2e (l2) from the fp32 oracle's" % (k, v)
+
+
 def test_wgangp_100_iterations_teacher_forced_full_width_dcgan64(gpu, capsys):
     """The north-star statement at the north-star layer sizes: WGAN-GP, DCGAN-64 with ngf = ndf = 64 on 3x64x64,
     z = 100, RMSprop lr 1e-4 / 5e-5, 100 iterations at batch 64 (what the CPU oracle finishes in about a minute),
