@@ -10,7 +10,7 @@ dominant kernel's measured traffic next to its algorithmic work.
 HBM bytes follow the gfx950 reading of the counters: FETCH_SIZE and WRITE_SIZE are in KiB, and FETCH_SIZE counts a
 128-byte request of a wide (16 B per lane) coalesced read as 64 bytes, so reads = 2 * FETCH_SIZE * 1024 (an upper
 bound for kernels with narrow reads), writes = WRITE_SIZE * 1024. Infinity-cache hits are included in both.
-MFMA flops = SQ_INSTS_VALU_MFMA_MOPS_F32 * 512.  Effective clock = GRBM_GUI_ACTIVE / 8 XCDs / duration.
+MFMA flops = (SQ_INSTS_VALU_MFMA_MOPS_F32 + SQ_INSTS_VALU_MFMA_MOPS_BF16, whichever the pass collected) * 512.  Effective clock = GRBM_GUI_ACTIVE / 8 XCDs / duration.
 """
 import collections
 import csv
@@ -65,7 +65,7 @@ def main():
     with open(out, "w") as f:
         f.write("# rocprofv3 --kernel-trace --pmc (3 passes) : %s\n\n" % cmd)
         f.write("Per launch averages. read = 2 x FETCH_SIZE KiB (gfx950 wide-read correction), write = WRITE_SIZE KiB, "
-                "both include infinity-cache hits; MFMA TFLOP/s = MOPS_F32 x 512 / duration; clock = GRBM_GUI_ACTIVE / 8 "
+                "both include infinity-cache hits; MFMA TFLOP/s = MOPS_{F32,BF16} x 512 / duration; clock = GRBM_GUI_ACTIVE / 8 "
                 "/ duration (reads high for launches well under 0.3 ms); durations are those of the profiled (serialised) "
                 "pass 1.\n\n")
         f.write("| kernel | calls | avg us | read MB | write MB | GB/s | MFMA TFLOP/s | MFMA busy / CU busy | clock GHz |\n")
@@ -78,7 +78,7 @@ def main():
             rd = 2.0 * a["FETCH_SIZE"] * 1024 / max(a["FETCH_SIZE_calls"], 1)
             wr = a["WRITE_SIZE"] * 1024 / max(a["WRITE_SIZE_calls"], 1)
             gbs = (rd + wr) / (us * 1e-6) / 1e9
-            tf = a["SQ_INSTS_VALU_MFMA_MOPS_F32"] * 512 / n / (us * 1e-6) / 1e12
+            tf = (a["SQ_INSTS_VALU_MFMA_MOPS_F32"] + a["SQ_INSTS_VALU_MFMA_MOPS_BF16"]) * 512 / n / (us * 1e-6) / 1e12
             busy = a["SQ_VALU_MFMA_BUSY_CYCLES"] / a["SQ_BUSY_CU_CYCLES"] if a["SQ_BUSY_CU_CYCLES"] else 0.0
             clk = a["GRBM_GUI_ACTIVE"] / 8 / a["ns"]
             f.write("| `%s` | %d | %.1f | %.1f | %.1f | %.0f | %s | %s | %.2f |\n" % (
