@@ -28,7 +28,6 @@
 
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 enum { PREC_F32 = 0, PREC_BF16 = 1, PREC_SPLIT = 2 };   // PREC_SPLIT is served by pgemm.h; here it runs as f32
 

@@ -4,8 +4,6 @@
 
 #include <string.h>
 
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-
 char* vg_error_buffer() {
   static thread_local char buf[512] = {0};
   return buf;

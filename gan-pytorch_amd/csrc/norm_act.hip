@@ -57,15 +57,16 @@ __global__ void __launch_bounds__(256) colreduce_partial(F f, int M, int C, int 
 #pragma unroll
       for (int e = 0; e < VEC; ++e) red[(v * VEC + e) * 256 + tid] = (double)acc[v][e];
     __syncthreads();
-    if (ty == 0 && cg < cg_hi) {
-#pragma unroll
-      for (int v = 0; v < NV; ++v)
-#pragma unroll
-        for (int e = 0; e < VEC; ++e) {
-          double s = 0.0;
-          for (int y = 0; y < TY; ++y) s += red[(v * VEC + e) * 256 + y * TX + tx];
-          partial[((size_t)v * nblk + blockIdx.x) * C + cg * VEC + e] = s;
-        }
+    // NV * VEC * TX independent sums over the TY row lanes, one per thread (each still added in row-lane order, so the
+    // result does not depend on how the sums are dealt out): done by 16 threads this tail took as long as the loads
+    for (int q = tid; q < NV * VEC * TX; q += 256) {
+      const int ve = q / TX, qx = q - ve * TX;
+      if (cg0 + qx < cg_hi) {
+        double s = 0.0;
+        for (int y = 0; y < TY; ++y) s += red[ve * 256 + y * TX + qx];
+        const int v = ve / VEC, e = ve - v * VEC;
+        partial[((size_t)v * nblk + blockIdx.x) * C + (cg0 + qx) * VEC + e] = s;
+      }
     }
     __syncthreads();
   }
