@@ -26,6 +26,7 @@ struct PgemmParams {
   const __bf16* Ap;              // plane 0 of operand A (fwd: x, dgrad: gy, wgrad: gy)
   const __bf16* Bp;              // plane 0 of operand B (fwd: w, dgrad: w, wgrad: x)
   long long a_plane, b_plane;    // elements from one plane to the next
+  unsigned a_bytes, b_bytes;     // bytes from plane 0 to the end of the last plane (below 2 GiB: pgemm_prepare)
 };
 
 static __device__ __attribute__((aligned(16))) unsigned int vg_zero_page_u[4] = {0u, 0u, 0u, 0u};  // never written
@@ -206,15 +207,21 @@ __global__ void __launch_bounds__(NW * 64) pgemm_kernel(const PgemmParams pp) {
   // two register stages: tile t travels through stage t % 2, so its loads are in flight for two k-steps
   u32x4 ra[2][UA][NP], rb[2][UB][NP];
 
-  // predicated 16-byte load of the same offset in every plane; an invalid unit reads the zero page
-  auto ld_planes = [&](const __bf16* base, long long pstride, size_t off, bool ok, u32x4 (&dst)[NP]) {
+  // Predicated 16-byte load of the same element offset in every plane, as a range-checked buffer load on a 32-bit
+  // byte offset: a unit that must not be read gets an offset beyond the buffer and comes back as zeros (no 64-bit
+  // address arithmetic and no pointer select in the k-walk; with bf16 MFMAs a k-step's address arithmetic on the vector
+  // ALU takes as long as its matrix work).
+  constexpr unsigned OOB = 0x80000000u;
+  const __amdgpu_buffer_rsrc_t rsrcA = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(pp.Ap), 0, (int)pp.a_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrcB = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(pp.Bp), 0, (int)pp.b_bytes, 0x00020000);
+  const unsigned a_pbytes = (unsigned)pp.a_plane * 2u, b_pbytes = (unsigned)pp.b_plane * 2u;
+  auto ld_planes = [&](const __amdgpu_buffer_rsrc_t& rs, unsigned pbytes, unsigned off, bool ok, u32x4 (&dst)[NP]) {
 #pragma unroll
     for (int q = 0; q < NP; ++q) {
       if constexpr ((PG_ABLATE & 1) != 0) {
-        dst[q] = u32x4{(unsigned)off, 0u, 0u, 0u};
+        dst[q] = u32x4{off, 0u, 0u, 0u};
       } else {
-        const void* ptr = ok ? (const void*)(base + (size_t)q * pstride + off) : (const void*)vg_zero_page_u;
-        dst[q] = *reinterpret_cast<const u32x4*>(ptr);
+        dst[q] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(ok ? off * 2u + q * pbytes : OOB), 0, 0));
       }
     }
   };
@@ -230,11 +237,11 @@ __global__ void __launch_bounds__(NW * 64) pgemm_kernel(const PgemmParams pp) {
         if constexpr (MODE == MODE_FWD) {
           const int hi = a_h[i] + ak_ta, wi = a_w[i] + ak_tb;
           const bool ok = kvalid && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
-          ld_planes(pp.Ap, pp.a_plane, (size_t)(a_img[i] + hi * p.W + wi) * p.Ci + ak_c, ok, ra[st][i]);
+          ld_planes(rsrcA, a_pbytes, (unsigned)(a_img[i] + hi * p.W + wi) * (unsigned)p.Ci + (unsigned)ak_c, ok, ra[st][i]);
         } else {
           const int ho = a_h[i] - ak_ta, wo = a_w[i] - ak_tb;
           const bool ok = kvalid && (unsigned)ho < (unsigned)p.Ho && (unsigned)wo < (unsigned)p.Wo;
-          ld_planes(pp.Ap, pp.a_plane, (size_t)(a_img[i] + ho * p.Wo + wo) * p.Co + ak_c, ok, ra[st][i]);
+          ld_planes(rsrcA, a_pbytes, (unsigned)(a_img[i] + ho * p.Wo + wo) * (unsigned)p.Co + (unsigned)ak_c, ok, ra[st][i]);
         }
       }
     } else {
@@ -243,7 +250,7 @@ __global__ void __launch_bounds__(NW * 64) pgemm_kernel(const PgemmParams pp) {
 #pragma unroll
       for (int i = 0; i < UA; ++i) {
         const int pix = kb + krowA(i);
-        ld_planes(pp.Ap, pp.a_plane, (size_t)pix * p.Co + m8, krowA(i) < BK && pix < kend && m8 < p.Co, ra[st][i]);
+        ld_planes(rsrcA, a_pbytes, (unsigned)pix * (unsigned)p.Co + (unsigned)m8, krowA(i) < BK && pix < kend && m8 < p.Co, ra[st][i]);
       }
     }
     // ---------------- B ----------------
@@ -253,7 +260,7 @@ __global__ void __launch_bounds__(NW * 64) pgemm_kernel(const PgemmParams pp) {
 #pragma unroll
       for (int i = 0; i < UB; ++i) {
         const int n = n0 + rowB(i);
-        ld_planes(pp.Bp, pp.b_plane, (size_t)n * Ktot + k8, rowB(i) < BN && n < p.Ncols && k8 < kend, rb[st][i]);
+        ld_planes(rsrcB, b_pbytes, (unsigned)n * (unsigned)Ktot + (unsigned)k8, rowB(i) < BN && n < p.Ncols && k8 < kend, rb[st][i]);
       }
     } else if constexpr (MODE == MODE_DGRAD) {
       // weights w[co][kh][kw][ci] read as B[k=(tap,co)][n=ci]
@@ -262,8 +269,8 @@ __global__ void __launch_bounds__(NW * 64) pgemm_kernel(const PgemmParams pp) {
         const int k = kb + krowB(i);
         const int bta = vg_div_small(bk_t[i], inv_ntw), btb = bk_t[i] - bta * ntw;
         const int kh = cls_h + p.sh * bta, kw = cls_w + p.sw * btb;
-        const size_t base = ((size_t)(bk_co[i] * p.KH + kh) * p.KW + kw) * p.Ci;
-        ld_planes(pp.Bp, pp.b_plane, base + bn8, krowB(i) < BK && k < kend && bn8 < p.Ncols, rb[st][i]);
+        const unsigned base = (unsigned)((bk_co[i] * p.KH + kh) * p.KW + kw) * (unsigned)p.Ci;
+        ld_planes(rsrcB, b_pbytes, base + (unsigned)bn8, krowB(i) < BK && k < kend && bn8 < p.Ncols, rb[st][i]);
       }
     } else {
       // wgrad B = x window, tile [k=pixel][n=(kh,kw,ci)]
@@ -273,7 +280,7 @@ __global__ void __launch_bounds__(NW * 64) pgemm_kernel(const PgemmParams pp) {
         const int bpn = vg_div_small(bp_row[i], inv_ho), bpho = bp_row[i] - bpn * p.Ho;
         const int hi = bpho * p.sh - p.ph + b_ta, wi = bp_wo[i] * p.sw - p.pw + b_tb;
         const bool ok = krowB(i) < BK && pix < kend && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
-        ld_planes(pp.Bp, pp.b_plane, (size_t)((bpn * p.H + hi) * p.W + wi) * p.Ci + b_ci, ok, rb[st][i]);
+        ld_planes(rsrcB, b_pbytes, (unsigned)((bpn * p.H + hi) * p.W + wi) * (unsigned)p.Ci + (unsigned)b_ci, ok, rb[st][i]);
       }
     }
     // ---------------- advance the k-walk by one tile ----------------
@@ -631,5 +638,12 @@ static inline int pgemm_prepare(PgemmParams& pp, const float* A, long long a_ele
   pp.Bp = (const __bf16*)b_planes;
   pp.a_plane = vg_plane_stride(a_elems);
   pp.b_plane = vg_plane_stride(b_elems);
+  // the kernel addresses every operand with 32-bit byte offsets into a range-checked buffer; an offset with the top bit
+  // set stands for "do not read", so the planes of an operand together must stay below 2 GiB
+  const long long a_bytes = ((long long)(np - 1) * pp.a_plane + a_elems) * 2, b_bytes = ((long long)(np - 1) * pp.b_plane + b_elems) * 2;
+  if (a_bytes >= (1LL << 31) || b_bytes >= (1LL << 31))
+    return vg_fail(VG_ERR_INVALID, "%s: the bf16 kernels address operands with 31-bit byte offsets; an operand's planes are 2 GiB or larger", who);
+  pp.a_bytes = (unsigned)a_bytes;
+  pp.b_bytes = (unsigned)b_bytes;
   return 0;
 }
