@@ -92,6 +92,11 @@ extern "C" int vg_split_planes_f32(const float* in, long long elements, int prec
 // cases elsewhere.
 int vg_planes_applicable(int mode, const vg_conv_geom* g) {
   if (g->Ci % 8 != 0 || g->Co % 8 != 0) return 0;
+  // the kernel's index arithmetic uses 24-bit products: rows of images, taps times channels and the like stay below 2^24
+  const long long lim = 1LL << 24;
+  if ((long long)g->N * g->H >= lim || (long long)g->N * g->Ho >= lim || (long long)g->Co * g->kh * g->kw >= lim ||
+      (long long)g->kh * g->W + g->kw >= lim || (long long)g->Ci >= lim || (long long)g->W >= lim)
+    return 0;
   const int ncols = mode == 0 ? g->Co : (mode == 1 ? g->Ci : g->kh * g->kw * g->Ci);
   return ncols > 32 ? 1 : 0;
 }

@@ -131,8 +131,14 @@ __global__ void __launch_bounds__(NW * 64) pgemm_kernel(const PgemmParams pp) {
   auto krowA = [&](int i) -> int { return tid / TPKA + (NT / TPKA) * i; };  // [k][row] tiles
   auto krowB = [&](int i) -> int { return tid / TPKB + (NT / TPKB) * i; };
 
-  // ---- A loader state ([row][k]: fwd / dgrad) ----
-  int a_img[A_MC ? 1 : UA], a_h[A_MC ? 1 : UA], a_w[A_MC ? 1 : UA];
+  // Products of two non-negative factors below 2^24 (vg_planes_applicable vouches for the extents): v_mul_u32_u24 runs at
+  // full rate, the 32-bit v_mul_lo_u32 at a quarter of it, and the k-walk below is made of such products.
+  auto m24 = [](int a, int b) -> int { return (int)__umul24((unsigned)a, (unsigned)b); };
+
+  // ---- A loader state ([row][k]: fwd / dgrad): the row's element offset at tap (0, 0), channel 0 (taps and channels
+  // are added per k-step with one product shared by all rows of the thread), and its window origin for the bounds ----
+  unsigned a_base[A_MC ? 1 : UA];
+  int a_h[A_MC ? 1 : UA], a_w[A_MC ? 1 : UA];
   const bool fast = p.fast_div != 0;
   const int roww = (MODE == MODE_FWD) ? p.Wo : Wc;
   const int plane = (MODE == MODE_FWD) ? p.Ho * p.Wo : Hc * Wc;
@@ -141,20 +147,20 @@ __global__ void __launch_bounds__(NW * 64) pgemm_kernel(const PgemmParams pp) {
 #pragma unroll
     for (int i = 0; i < UA; ++i) {
       const int m = m0 + rowA(i);
-      a_img[i] = 0;
+      a_base[i] = 0u;
       a_w[i] = 0;
       a_h[i] = -(1 << 28);
       if (rowA(i) < BM && m < M) {
         const int n = vg_div_row(m, plane, inv_plane, fast), rem = m - n * plane;
         const int a = vg_div_row(rem, roww, inv_roww, fast), b = rem - a * roww;
         if constexpr (MODE == MODE_FWD) {
-          a_img[i] = n * p.H * p.W;
           a_h[i] = a * p.sh - p.ph;
           a_w[i] = b * p.sw - p.pw;
+          a_base[i] = (unsigned)((n * p.H + a_h[i]) * p.W + a_w[i]) * (unsigned)p.Ci;      // (wraps for a padded origin)
         } else {
-          a_img[i] = n * p.Ho * p.Wo;
           a_h[i] = a + base_h;
           a_w[i] = b + base_w;
+          a_base[i] = (unsigned)((n * p.Ho + a_h[i]) * p.Wo + a_w[i]) * (unsigned)p.Co;
         }
       }
     }
@@ -192,6 +198,19 @@ __global__ void __launch_bounds__(NW * 64) pgemm_kernel(const PgemmParams pp) {
       bk_co[i] = k - bk_t[i] * p.Co;
     }
   }
+  // wgrad A = gy[pixel][co]: the unit's element offset, advanced by BK pixels per tile
+  unsigned a_off[A_MC ? UA : 1];
+  if constexpr (A_MC) {
+#pragma unroll
+    for (int i = 0; i < UA; ++i) a_off[i] = (unsigned)(kbeg + krowA(i)) * (unsigned)p.Co + (unsigned)(m0 + 8 * (tid % TPKA));
+  }
+  // fwd B = w[co][k]: the row's first element
+  unsigned b_rowbase[B_MC ? 1 : UB];
+  if constexpr (!B_MC) {
+#pragma unroll
+    for (int i = 0; i < UB; ++i) b_rowbase[i] = (unsigned)(n0 + rowB(i)) * (unsigned)Ktot;
+  }
+  const int khkw = p.KH * p.KW;
   int bp_row[(MODE == MODE_WGRAD) ? UB : 1], bp_wo[(MODE == MODE_WGRAD) ? UB : 1];
   const int w_steps = (MODE == MODE_WGRAD) ? BK / p.Wo : 0, w_rem = (MODE == MODE_WGRAD) ? BK - w_steps * p.Wo : 0;
   const float inv_ho = 1.0f / (float)p.Ho;
@@ -231,17 +250,21 @@ __global__ void __launch_bounds__(NW * 64) pgemm_kernel(const PgemmParams pp) {
     // ---------------- A ----------------
     if constexpr (!A_MC) {
       const bool kvalid = kb + 8 * (tid % KV) < kend;
-      const int ak_ta = vg_div_small(ak_t, inv_ntw), ak_tb = ak_t - ak_ta * ntw;
+      const int ak_ta = vg_div_small(ak_t, inv_ntw), ak_tb = ak_t - m24(ak_ta, ntw);
+      // what tap (ak_ta, ak_tb) and channel ak_c add to a row's offset: one product pair per k-step, not per row
+      const unsigned tap_off = (MODE == MODE_FWD)
+                                   ? (unsigned)m24(m24(ak_ta, p.W) + ak_tb, p.Ci) + (unsigned)ak_c
+                                   : (unsigned)ak_c - (unsigned)m24(m24(ak_ta, p.Wo) + ak_tb, p.Co);
 #pragma unroll
       for (int i = 0; i < UA; ++i) {
         if constexpr (MODE == MODE_FWD) {
           const int hi = a_h[i] + ak_ta, wi = a_w[i] + ak_tb;
           const bool ok = kvalid && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
-          ld_planes(rsrcA, a_pbytes, (unsigned)(a_img[i] + hi * p.W + wi) * (unsigned)p.Ci + (unsigned)ak_c, ok, ra[st][i]);
+          ld_planes(rsrcA, a_pbytes, a_base[i] + tap_off, ok, ra[st][i]);
         } else {
           const int ho = a_h[i] - ak_ta, wo = a_w[i] - ak_tb;
           const bool ok = kvalid && (unsigned)ho < (unsigned)p.Ho && (unsigned)wo < (unsigned)p.Wo;
-          ld_planes(rsrcA, a_pbytes, (unsigned)(a_img[i] + ho * p.Wo + wo) * (unsigned)p.Co + (unsigned)ak_c, ok, ra[st][i]);
+          ld_planes(rsrcA, a_pbytes, a_base[i] + tap_off, ok, ra[st][i]);
         }
       }
     } else {
@@ -250,7 +273,8 @@ __global__ void __launch_bounds__(NW * 64) pgemm_kernel(const PgemmParams pp) {
 #pragma unroll
       for (int i = 0; i < UA; ++i) {
         const int pix = kb + krowA(i);
-        ld_planes(rsrcA, a_pbytes, (unsigned)pix * (unsigned)p.Co + (unsigned)m8, krowA(i) < BK && pix < kend && m8 < p.Co, ra[st][i]);
+        ld_planes(rsrcA, a_pbytes, a_off[i], krowA(i) < BK && pix < kend && m8 < p.Co, ra[st][i]);
+        a_off[i] += (unsigned)BK * (unsigned)p.Co;
       }
     }
     // ---------------- B ----------------
@@ -260,16 +284,16 @@ __global__ void __launch_bounds__(NW * 64) pgemm_kernel(const PgemmParams pp) {
 #pragma unroll
       for (int i = 0; i < UB; ++i) {
         const int n = n0 + rowB(i);
-        ld_planes(rsrcB, b_pbytes, (unsigned)n * (unsigned)Ktot + (unsigned)k8, rowB(i) < BN && n < p.Ncols && k8 < kend, rb[st][i]);
+        ld_planes(rsrcB, b_pbytes, b_rowbase[i] + (unsigned)k8, rowB(i) < BN && n < p.Ncols && k8 < kend, rb[st][i]);
       }
     } else if constexpr (MODE == MODE_DGRAD) {
       // weights w[co][kh][kw][ci] read as B[k=(tap,co)][n=ci]
 #pragma unroll
       for (int i = 0; i < UB; ++i) {
         const int k = kb + krowB(i);
-        const int bta = vg_div_small(bk_t[i], inv_ntw), btb = bk_t[i] - bta * ntw;
-        const int kh = cls_h + p.sh * bta, kw = cls_w + p.sw * btb;
-        const unsigned base = (unsigned)((bk_co[i] * p.KH + kh) * p.KW + kw) * (unsigned)p.Ci;
+        const int bta = vg_div_small(bk_t[i], inv_ntw), btb = bk_t[i] - m24(bta, ntw);
+        const int kh = cls_h + m24(p.sh, bta), kw = cls_w + m24(p.sw, btb);
+        const unsigned base = (unsigned)m24(m24(bk_co[i], khkw) + m24(kh, p.KW) + kw, p.Ci);
         ld_planes(rsrcB, b_pbytes, base + (unsigned)bn8, krowB(i) < BK && k < kend && bn8 < p.Ncols, rb[st][i]);
       }
     } else {
@@ -277,10 +301,11 @@ __global__ void __launch_bounds__(NW * 64) pgemm_kernel(const PgemmParams pp) {
 #pragma unroll
       for (int i = 0; i < UB; ++i) {
         const int pix = kb + krowB(i);
-        const int bpn = vg_div_small(bp_row[i], inv_ho), bpho = bp_row[i] - bpn * p.Ho;
-        const int hi = bpho * p.sh - p.ph + b_ta, wi = bp_wo[i] * p.sw - p.pw + b_tb;
+        const int bpn = vg_div_small(bp_row[i], inv_ho), bpho = bp_row[i] - m24(bpn, p.Ho);
+        const int hi = m24(bpho, p.sh) - p.ph + b_ta, wi = m24(bp_wo[i], p.sw) - p.pw + b_tb;
         const bool ok = krowB(i) < BK && pix < kend && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
-        ld_planes(rsrcB, b_pbytes, (unsigned)((bpn * p.H + hi) * p.W + wi) * (unsigned)p.Ci + (unsigned)b_ci, ok, rb[st][i]);
+        // (hi, wi are in range wherever the unit is read, so the factors below are non-negative there)
+        ld_planes(rsrcB, b_pbytes, (unsigned)(m24(m24(bpn, p.H) + hi, p.W) + wi) * (unsigned)p.Ci + (unsigned)b_ci, ok, rb[st][i]);
       }
     }
     // ---------------- advance the k-walk by one tile ----------------
