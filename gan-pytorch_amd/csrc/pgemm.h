@@ -43,8 +43,11 @@ typedef short s16x4 __attribute__((ext_vector_type(4)));
 // OUT_H: the result leaves as bf16 (round to nearest even) instead of f32 - the convolution of a network whose
 // activations are stored as bf16. Two neighbouring lanes (columns c, c + 1) exchange one accumulator per pair of rows,
 // so that every lane stores a packed pair of columns: 4-byte stores, 16 lanes per 64-byte row segment.
+// Single-plane forward / input-gradient instances are held to 128 registers (four waves per SIMD, i.e. two 8-wave blocks
+// per CU: the 128 x 128 tile otherwise takes 136-146 and runs one block per CU; measured 25.7 vs 28.0 us and 28.4 vs
+// 31.9 us). Not the weight gradient: its grid is one block per CU anyway and the few spills cost it 15%.
 template <int MODE, int BM, int BN, int WAVES_M, int NP, int NW, int BK_ = 32, bool OUT_H = false>
-__global__ void __launch_bounds__(NW * 64) pgemm_kernel(const PgemmParams pp) {
+__global__ void __launch_bounds__(NW * 64, (NP == 1 && NW == 8 && MODE != MODE_WGRAD) ? 4 : 1) pgemm_kernel(const PgemmParams pp) {
   const IgemmParams& p = pp.g;
   constexpr int NT = NW * 64;
   constexpr int BK = BK_;                          // k extent of a staged tile: 32, or 64 where LDS allows (one plane)
