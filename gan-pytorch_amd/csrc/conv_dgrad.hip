@@ -63,6 +63,20 @@ extern "C" int vg_conv2d_dgrad_h(const vg_conv_geom* g, const void* gy, const vo
                          nullptr, nullptr, stream, true);
 }
 
+// vg_conv2d_dgrad_h followed by the backward of a ReLU / LeakyReLU that sits in FRONT of the convolution (its output
+// act_out, bf16, laid out like gx): the mask is applied to the f32 result before it is rounded and stored.
+extern "C" int vg_conv2d_dgrad_h_actmask(const vg_conv_geom* g, const void* gy, const void* w, void* gx, const void* act_out,
+                                         int act, float slope, void* stream) {
+  if (!vg_conv2d_h_applies(1, g))
+    return vg_fail(VG_ERR_INVALID, "vg_conv2d_dgrad_h_actmask: this geometry is not served on bf16 tensors (vg_conv2d_h_applies)");
+  VG_REQUIRE(gy && w && gx && act_out && vg_aligned16(gy) && vg_aligned16(w) && vg_aligned16(gx) && vg_aligned16(act_out),
+             "vg_conv2d_dgrad_h_actmask: null or misaligned tensor");
+  VG_REQUIRE(act == VG_ACT_RELU || act == VG_ACT_LRELU, "vg_conv2d_dgrad_h_actmask: only ReLU / LeakyReLU have a slope mask");
+  const VgNormBwdSrc nb{(const float*)act_out, nullptr, nullptr, nullptr, nullptr, act, slope};
+  return conv_dgrad_impl(g, (const float*)gy, (const float*)w, nullptr, (float*)gx, VG_PREC_BF16, nullptr, 0, gy, w, nullptr,
+                         nullptr, &nb, stream, true);
+}
+
 static int conv_dgrad_impl(const vg_conv_geom* g, const float* gy, const float* w, const float* bias, float* gx,
                            int precision, void* workspace, size_t workspace_bytes, const void* gy_planes,
                            const void* w_planes, double* stats, int* stats_written, const VgNormBwdSrc* nb, void* stream,
@@ -108,6 +122,15 @@ static int conv_dgrad_impl(const vg_conv_geom* g, const float* gy, const float* 
     if (int e = pgemm_prepare(pp, gy, (long long)g->N * g->Ho * g->Wo * g->Co, w, (long long)g->Co * g->kh * g->kw * g->Ci,
                               np, workspace, workspace_bytes, (hipStream_t)stream, "vg_conv2d_dgrad", gy_planes, w_planes))
       return e;
+    if (io_h && nb) {      // with the slope mask of the activation in front of the convolution (vg_conv2d_dgrad_h_actmask)
+      pp.mask_ref = (const __bf16*)(const void*)nb->x;
+      pp.mask_act = nb->act;
+      pp.mask_slope = nb->slope;
+      if (pgemm_launch<MODE_DGRAD, 1, true, true>(pp, bm, bn, grid, (hipStream_t)stream) != 0)
+        return vg_fail(VG_ERR_INVALID, "vg_conv2d_dgrad: no plane kernel for tile %dx%d", bm, bn);
+      VG_CHECK_LAUNCH("vg_conv2d_dgrad(planes, slope mask)");
+      return VG_OK;
+    }
     if ((io_h ? pgemm_launch<MODE_DGRAD, 1, true>(pp, bm, bn, grid, (hipStream_t)stream)
               : np == 3 ? pgemm_launch<MODE_DGRAD, 3>(pp, bm, bn, grid, (hipStream_t)stream)
                         : pgemm_launch<MODE_DGRAD, 1>(pp, bm, bn, grid, (hipStream_t)stream)) != 0)

@@ -27,6 +27,12 @@ struct PgemmParams {
   const __bf16* Bp;              // plane 0 of operand B (fwd: w, dgrad: w, wgrad: x)
   long long a_plane, b_plane;    // elements from one plane to the next
   unsigned a_bytes, b_bytes;     // bytes from plane 0 to the end of the last plane (below 2 GiB: pgemm_prepare)
+  // MASKED kernels (input gradient on bf16 tensors): the result is the gradient arriving at the OUTPUT of a ReLU /
+  // LeakyReLU whose output is mask_ref (laid out like the result); it is multiplied by the activation's slope at each
+  // position before it is stored, so what leaves is the gradient in front of the activation.
+  const __bf16* mask_ref;
+  int mask_act;
+  float mask_slope;
 };
 
 static __device__ __attribute__((aligned(16))) unsigned int vg_zero_page_u[4] = {0u, 0u, 0u, 0u};  // never written
@@ -46,8 +52,9 @@ typedef short s16x4 __attribute__((ext_vector_type(4)));
 // Single-plane forward / input-gradient instances are held to 128 registers (four waves per SIMD, i.e. two 8-wave blocks
 // per CU: the 128 x 128 tile otherwise takes 136-146 and runs one block per CU; measured 25.7 vs 28.0 us and 28.4 vs
 // 31.9 us). Not the weight gradient: its grid is one block per CU anyway and the few spills cost it 15%.
-template <int MODE, int BM, int BN, int WAVES_M, int NP, int NW, int BK_ = 32, bool OUT_H = false>
+template <int MODE, int BM, int BN, int WAVES_M, int NP, int NW, int BK_ = 32, bool OUT_H = false, bool MASKED = false>
 __global__ void __launch_bounds__(NW * 64, (NP == 1 && NW == 8 && MODE != MODE_WGRAD) ? 4 : 1) pgemm_kernel(const PgemmParams pp) {
+  static_assert(!MASKED || (OUT_H && MODE == MODE_DGRAD), "the slope mask belongs to the input gradient on bf16 tensors");
   const IgemmParams& p = pp.g;
   constexpr int NT = NW * 64;
   constexpr int BK = BK_;                          // k extent of a staged tile: 32, or 64 where LDS allows (one plane)
@@ -543,26 +550,48 @@ __global__ void __launch_bounds__(NW * 64, (NP == 1 && NW == 8 && MODE != MODE_W
   }
   if constexpr (OUT_H) {
     static_assert(MODE != MODE_WGRAD, "weight gradients leave as f32 slabs");
-    __bf16* outh = reinterpret_cast<__bf16*>(p.out) + n0 + wn * TN * 32 + (r & ~1);
+    const unsigned col_off = (unsigned)(n0 + wn * TN * 32 + (r & ~1));
+    __bf16* outh = reinterpret_cast<__bf16*>(p.out) + col_off;
     const bool odd = (lane & 1) != 0;
+    // rows of accumulators 2 e2 and 2 e2 + 1 are neighbours; the even lane stores the first, the odd lane the second.
+    // Element offsets of this lane's rows first (NO_ROW past the last row), and, for the MASKED form, all the words of
+    // the activation output it will need: loads issued inside the store loop would each be waited for before the store
+    // behind them, sixteen round trips in a row.
+    constexpr unsigned NO_ROW = 0xffffffffu;
+    unsigned roffs[TM][8];
+    unsigned yy[MASKED ? TM : 1][MASKED ? 8 : 1][MASKED ? TN : 1];
 #pragma unroll
     for (int mi = 0; mi < TM; ++mi) {
       const int row_t = m0 + (wm * TM + mi) * 32 + 4 * h;
 #pragma unroll
       for (int e2 = 0; e2 < 8; ++e2) {
-        // rows of accumulators 2 e2 and 2 e2 + 1 are neighbours; the even lane stores the first, the odd lane the second
         const int dr = ((2 * e2) & 3) + 8 * ((2 * e2) >> 2) + (odd ? 1 : 0);
         const int row = row_t + dr;
-        const bool rok = row < M;
-        size_t roff;
-        if constexpr (MODE == MODE_DGRAD) {
-          const int rc = rok ? row : 0;
-          const int n = vg_div_row(rc, plane, inv_plane, fast), rem = rc - n * plane;
-          const int ii = vg_div_row(rem, roww, inv_roww, fast), jj = rem - ii * roww;
-          roff = (size_t)((n * p.H + ii * p.sh + off_h) * p.W + jj * p.sw + off_w) * p.Ncols;
-        } else {
-          roff = (size_t)row * p.Ncols;
+        unsigned roff = NO_ROW;
+        if (row < M) {
+          if constexpr (MODE == MODE_DGRAD) {
+            const int n = vg_div_row(row, plane, inv_plane, fast), rem = row - n * plane;
+            const int ii = vg_div_row(rem, roww, inv_roww, fast), jj = rem - ii * roww;
+            roff = (unsigned)((n * p.H + ii * p.sh + off_h) * p.W + jj * p.sw + off_w) * (unsigned)p.Ncols;
+          } else {
+            roff = (unsigned)row * (unsigned)p.Ncols;
+          }
         }
+        roffs[mi][e2] = roff;
+        if constexpr (MASKED) {
+#pragma unroll
+          for (int ni = 0; ni < TN; ++ni)
+            yy[mi][e2][ni] = (roff != NO_ROW && cok[ni])
+                                 ? *reinterpret_cast<const unsigned int*>(pp.mask_ref + col_off + roff + ni * 32) : 0u;
+        }
+      }
+    }
+    const float low = pp.mask_act == VG_ACT_RELU ? 0.f : pp.mask_slope;
+#pragma unroll
+    for (int mi = 0; mi < TM; ++mi) {
+#pragma unroll
+      for (int e2 = 0; e2 < 8; ++e2) {
+        const unsigned roff = roffs[mi][e2];
 #pragma unroll
         for (int ni = 0; ni < TN; ++ni) {
           float v0 = acc[mi][ni][2 * e2], v1 = acc[mi][ni][2 * e2 + 1];
@@ -573,8 +602,12 @@ __global__ void __launch_bounds__(NW * 64, (NP == 1 && NW == 8 && MODE != MODE_W
           const float keep = odd ? v1 : v0, send = odd ? v0 : v1;
           const float recv = __builtin_bit_cast(
               float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, send), 0xB1, 0xF, 0xF, false));   // lane ^ 1
-          const f32x2 pr = {odd ? recv : keep, odd ? keep : recv};
-          if (rok && cok[ni])
+          f32x2 pr = {odd ? recv : keep, odd ? keep : recv};
+          if constexpr (MASKED) {       // the activation's output at the two positions this lane stores: positive -> slope 1
+            pr[0] *= __builtin_bit_cast(float, yy[mi][e2][ni] << 16) > 0.f ? 1.f : low;
+            pr[1] *= __builtin_bit_cast(float, yy[mi][e2][ni] & 0xffff0000u) > 0.f ? 1.f : low;
+          }
+          if (roff != NO_ROW && cok[ni])
             *reinterpret_cast<unsigned int*>(outh + roff + ni * 32) =
                 __builtin_bit_cast(unsigned int, __builtin_convertvector(pr, bf16x2));
         }
@@ -614,13 +647,13 @@ __global__ void __launch_bounds__(NW * 64, (NP == 1 && NW == 8 && MODE != MODE_W
 }
 
 // Tiles served: 128x128, 128x64, 64x128 (eight waves) and 64x64 (four waves).
-template <int MODE, int NP, bool OUT_H = false>
+template <int MODE, int NP, bool OUT_H = false, bool MASKED = false>
 static inline int pgemm_launch(const PgemmParams& pp, int bm, int bn, dim3 grid, hipStream_t st) {
   constexpr int BK = NP == 1 ? 64 : 32;     // a single plane leaves room for 64-deep tiles: half the barriers per flop
-  if (bm == 128 && bn == 128) vg_launch_timed(pgemm_kernel<MODE, 128, 128, 2, NP, 8, BK, OUT_H>, grid, dim3(512), 0, st, pp);
-  else if (bm == 128 && bn == 64) vg_launch_timed(pgemm_kernel<MODE, 128, 64, 4, NP, 8, BK, OUT_H>, grid, dim3(512), 0, st, pp);
-  else if (bm == 64 && bn == 128) vg_launch_timed(pgemm_kernel<MODE, 64, 128, 2, NP, 8, BK, OUT_H>, grid, dim3(512), 0, st, pp);
-  else if (bm == 64 && bn == 64) vg_launch_timed(pgemm_kernel<MODE, 64, 64, 2, NP, 4, BK, OUT_H>, grid, dim3(256), 0, st, pp);
+  if (bm == 128 && bn == 128) vg_launch_timed(pgemm_kernel<MODE, 128, 128, 2, NP, 8, BK, OUT_H, MASKED>, grid, dim3(512), 0, st, pp);
+  else if (bm == 128 && bn == 64) vg_launch_timed(pgemm_kernel<MODE, 128, 64, 4, NP, 8, BK, OUT_H, MASKED>, grid, dim3(512), 0, st, pp);
+  else if (bm == 64 && bn == 128) vg_launch_timed(pgemm_kernel<MODE, 64, 128, 2, NP, 8, BK, OUT_H, MASKED>, grid, dim3(512), 0, st, pp);
+  else if (bm == 64 && bn == 64) vg_launch_timed(pgemm_kernel<MODE, 64, 64, 2, NP, 4, BK, OUT_H, MASKED>, grid, dim3(256), 0, st, pp);
   else return -1;
   return 0;
 }

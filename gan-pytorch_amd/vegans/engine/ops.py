@@ -546,7 +546,7 @@ class _ActivationGradient:
         self.announced, self.token = True, None
 
     def take_token(self):
-        if not self.announced or _precision != 0:
+        if not self.announced or not (_precision == 0 or _mode == "bf16") or os.environ.get("VEGANS_HIP_ACT_MASK") == "0":
             return None
         self.announced = False
         self.token = {"accepted": False}
@@ -886,8 +886,15 @@ class ConvDgradMaskFn(Function):
         _check_shape(ref_m, g.x_shape(), "activation output")
         if w_m.numel() != g.w_numel():
             raise _hip.HipError("weight has %d elements, geometry expects %d" % (w_m.numel(), g.w_numel()))
+        if _mode == "bf16" and ref_m.dtype == BF16 and _h_contraction(1, g, gy_m, w_m, BF16):
+            gh = _cast_raw(gy_m, BF16)
+            wh = plane_cache.bf16_copy(w_m) if w_m.dtype == F32 else w_m
+            gx = _new_act(g.N, g.Ci, g.H, g.W, gy_m, g.flat, BF16)
+            _launch_conv(1, g, lambda: call("vg_conv2d_dgrad_h_actmask", ctypes.byref(g.c), _p(gh), _p(wh), _p(gx), _p(ref_m),
+                                            act, c_float(slope), _stream()))
+            return gx
         if _precision != 0:
-            gx = raw_conv_dgrad(g, gy, w, None)
+            gx = raw_conv_dgrad(g, gy, w, None, out_dtype=ref_m.dtype)
             masked = ctypes.c_int(0)
         else:
             gx = _new_act(g.N, g.Ci, g.H, g.W, gy_m, g.flat)
@@ -896,7 +903,8 @@ class ConvDgradMaskFn(Function):
                                             _ptr(ref_m), act, c_float(slope), ctypes.byref(masked), _stream()))
         if not masked.value:
             plain, gx = gx, torch.empty_like(gx)
-            call("vg_act_bwd", _ptr(plain), _ptr(ref_m), _ptr(gx), c_size_t(gx.numel()), act, c_float(slope), _stream())
+            _same_storage(plain, ref_m)
+            call(_A("vg_act_bwd", gx), _p(plain), _p(ref_m), _p(gx), c_size_t(gx.numel()), act, c_float(slope), _stream())
         return gx
 
     @staticmethod

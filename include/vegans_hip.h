@@ -381,6 +381,11 @@ int vg_clamp(float* param, size_t n, float lo, float hi, void* stream);
 int vg_conv2d_h_applies(int mode, const vg_conv_geom* g);
 int vg_conv2d_fwd_h(const vg_conv_geom* g, const void* x, const void* w, const float* bias, void* y, void* stream);
 int vg_conv2d_dgrad_h(const vg_conv_geom* g, const void* gy, const void* w, const float* bias, void* gx, void* stream);
+/* vg_conv2d_dgrad_h with the slope mask of a ReLU / LeakyReLU in FRONT of the convolution applied before the store
+ * (as vg_conv2d_dgrad_actmask does for f32): gx = act'(act_out) * conv_transpose(gy, w); act_out is that activation's
+ * output, bf16, laid out like gx. Served wherever vg_conv2d_h_applies(1, g). */
+int vg_conv2d_dgrad_h_actmask(const vg_conv_geom* g, const void* gy, const void* w, void* gx, const void* act_out,
+                              int act, float slope, void* stream);
 size_t vg_conv2d_wgrad_h_workspace_bytes(const vg_conv_geom* g);
 int vg_conv2d_wgrad_partial_h(const vg_conv_geom* g, const void* gy, const void* x, float* gw, void* workspace,
                               size_t workspace_bytes, void* stream);

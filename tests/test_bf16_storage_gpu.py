@@ -348,3 +348,38 @@ def test_stem_h_kernels_equal_the_f32_kernels_on_the_same_values(gpu, case):
     _hip.call("vg_conv2d_wgrad_reduce", G, P(gw_h), P(ws), st)
     _hip.call("vg_conv2d_wgrad", G, P(gy_f), P(x), P(gw_f), P(ws), ctypes.c_size_t(nbytes), st)
     assert torch.equal(gw_h, gw_f), "stem weight gradient"
+
+
+@pytest.mark.parametrize("case", [(4, 64, 16, 16, 128, 4, 2, 1), (3, 64, 9, 7, 16, 3, 1, 1), (5, 40, 6, 6, 72, 3, 2, 0)])
+@pytest.mark.parametrize("act,slope", [(2, 0.2), (1, 0.0)])
+def test_h_input_gradient_with_slope_mask(gpu, case, act, slope):
+    """vg_conv2d_dgrad_h_actmask against vg_conv2d_dgrad_h followed by vg_act_bwd_h: identical where the slope is 1 or 0,
+    and within one rounding elsewhere (the fused form multiplies the f32 result and rounds once, the two-pass form
+    rounds the gradient, multiplies, and rounds again)."""
+    from vegans import _hip
+    from vegans.engine import ops
+    N, Ci, H, W, Co, k, s, p = case
+    CL = torch.channels_last
+    gen = torch.Generator().manual_seed(sum(case) + act)
+    geo = ops.Geom(N, H, W, Ci, Co, k, k, s, s, p, p)
+    G = ctypes.byref(geo.c)
+    assert _hip.load().vg_conv2d_h_applies(1, G)
+    gy = torch.randn(N, Co, geo.Ho, geo.Wo, generator=gen).bfloat16().to(gpu).contiguous(memory_format=CL)
+    w = (torch.randn(Co, Ci, k, k, generator=gen) * 0.1).bfloat16().to(gpu).contiguous(memory_format=CL)
+    ref = torch.randn(N, Ci, H, W, generator=gen).bfloat16().to(gpu).contiguous(memory_format=CL)
+    ref[0, :, 0, 0] = 0.0                                   # zeros take the lower branch
+    st = _hip._stream()
+    P = lambda t: ctypes.c_void_p(t.data_ptr())
+    fused = torch.empty_like(ref)
+    plain = torch.empty_like(ref)
+    two = torch.empty_like(ref)
+    _hip.call("vg_conv2d_dgrad_h_actmask", G, P(gy), P(w), P(fused), P(ref), act, ctypes.c_float(slope), st)
+    _hip.call("vg_conv2d_dgrad_h", G, P(gy), P(w), None, P(plain), st)
+    _hip.call("vg_act_bwd_h", P(plain), P(ref), P(two), ctypes.c_size_t(ref.numel()), act, ctypes.c_float(slope), st)
+    up = ref > 0
+    assert torch.equal(fused[up], plain[up])
+    if act == 1:
+        assert float(fused[~up].abs().max()) == 0.0
+    else:
+        # one rounding against two: up to a unit and a half in the last place of bf16
+        assert _rel_elem_err(fused.float(), two.float(), 1e-3) <= 2.05 * BF16_STORE
