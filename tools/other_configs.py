@@ -61,8 +61,14 @@ def main():
     m.train()
     X = m._to_device(cfg.synthetic_images(256, (3, 128, 128), seed=1))
     Z = torch.randn(256, 100, 1, 1, device="cuda")
-    dt = timed(m, (X, Z), steps)
-    print("LSGAN DCGAN-128, batch 256, Adam, fp32: %.2f ms/iteration, %.0f images/s" % (1e3 * dt, 256 / dt))
+    from vegans.engine import ops
+    for prec in ("fp32", "fp32_split", "bf16", "bf16_compute"):
+        previous = ops.set_matmul_precision(prec)
+        try:
+            dt = timed(m, (X, Z), steps)
+        finally:
+            ops.set_matmul_precision(previous)
+        print("LSGAN DCGAN-128, batch 256, Adam, %s: %.2f ms/iteration, %.0f images/s" % (prec, 1e3 * dt, 256 / dt))
     del m, X, Z
     torch.cuda.empty_cache()
 
@@ -76,8 +82,7 @@ def main():
     X = m._to_device(cfg.synthetic_images(64, (3, 256, 256), 0.0, 1.0, seed=1))
     y = m._to_device(cfg.synthetic_images(64, (3, 256, 256), 0.0, 1.0, seed=2))
     Z = torch.randn(64, 4, device="cuda")
-    for prec in ("fp32", "fp32_split", "bf16"):
-        from vegans.engine import ops
+    for prec in ("fp32", "fp32_split", "bf16", "bf16_compute"):
         previous = ops.set_matmul_precision(prec)
         try:
             dt = timed(m, (X, y, Z), steps)
