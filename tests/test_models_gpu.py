@@ -180,8 +180,22 @@ def _check_fit_against_fixture(name):
 BF16_LOSS_TOL = {"bf16_compute": 2e-2, "bf16": 5e-2}
 
 
-@pytest.mark.parametrize("mode", ["bf16", "bf16_compute"])
-@pytest.mark.parametrize("name", ["wgangp_dcgan64", "lsgan_dcgan16", "cwgangp_onehot", "pix2pix_unet", "lrgan_mlp"])
+_BF16_CASES = ["wgangp_dcgan64", "lsgan_dcgan16", "cwgangp_onehot", "pix2pix_unet", "lrgan_mlp"]
+# the bf16 data path on every other fixture without logging passes as well (weight clipping, MLP / BatchNorm1d stacks,
+# vector data with the pairwise penalty, conditional vectors, float64 inputs, the DCGAN-128 topology)
+_BF16_MORE = ["wgangp_dcgan16", "wgan_clip_dcgan16", "vanilla_mlp", "cwgan_clip_onehot", "cvanilla_onehot", "clsgan_onehot",
+              "pix2pix_small", "lsgan_dcgan128", "cwgangp_f64", "wgangp_vec", "clrgan_vec"]
+
+
+# Two free-running cases get a wider bound. wgangp_dcgan16: an 8-channel critic at initialisation, where the penalty
+# (norm - 1)^2 is 20 and dominates the loss; its relative error is that of the gradient norm times 2 norm / (norm - 1).
+# lsgan_dcgan128: the case whose own fp32 losses move by 2e-3 when its gradients are perturbed by 1e-6 (the fp32 test
+# gives it 5e-3 instead of 1e-4 for the same reason).
+_BF16_CASE_TOL = {"wgangp_dcgan16": 1e-1, "lsgan_dcgan128": 2e-1}
+
+
+@pytest.mark.parametrize("name,mode", [(n, m) for n in _BF16_CASES for m in ("bf16", "bf16_compute")] +
+                         [(n, "bf16") for n in _BF16_MORE])
 def test_bf16_mode_tracks_the_reference_within_its_tolerance(gpu, name, mode):
     """The bf16 modes against the reference's recorded fp32 run: every sub-step's losses within the mode's stated
     tolerance. "bf16" is the bf16 data path (feature maps and their gradients stored as bf16, f32 parameters,
@@ -210,7 +224,7 @@ def test_bf16_mode_tracks_the_reference_within_its_tolerance(gpu, name, mode):
         for k, v in want.items():
             if k == "RealFakeRatio":
                 continue
-            _close(float(got[k]), v, BF16_LOSS_TOL[mode], 1e-1, "%s step %d %s %s" % (mode, i, who, k))
+            _close(float(got[k]), v, _BF16_CASE_TOL.get(name, BF16_LOSS_TOL[mode]), 1e-1, "%s step %d %s %s" % (mode, i, who, k))
             worst = max(worst, abs(float(got[k]) - v) / max(abs(v), 1e-1))
     assert worst > 1e-6, "bf16 mode did not change a single loss: the mode was not active"
 
