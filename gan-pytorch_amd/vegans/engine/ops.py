@@ -41,7 +41,8 @@ BF16 = torch.bfloat16
 # ----------------------------------------------------------------------------------------------------------------
 def _p(t):
     """Device pointer of an activation of either storage type (None -> null). The kernel entry point is chosen with
-    `_A` from the same tensor, and `_same_storage` has checked that all activations of the call share the type."""
+    `_A` from one of the call's activations; every call site that hands a kernel more than one activation first
+    passes them through `_same_storage` (a bf16 buffer read as f32 would be read past its end)."""
     if t is None:
         return None
     if not t.is_cuda or t.dtype not in (F32, BF16):
@@ -1027,6 +1028,7 @@ class AddFn(Function):
             raise _hip.HipError("sum operands differ in shape: %s vs %s" % (tuple(a.shape), tuple(b.shape)))
         b = _cast_raw(b, a.dtype)
         out = torch.empty_like(a)
+        _same_storage(a, b, out)
         call(_A("vg_add", a), _p(a), _p(b), _p(out), c_size_t(a.numel()), _stream())
         return out
 
@@ -1068,6 +1070,7 @@ class BatchNormTrainFn(Function):
                      _ptr(running_mean), _ptr(running_var), counter,
                      ctypes.c_void_p(ws.data_ptr()), c_size_t(nbytes), _stream())
         y = torch.empty_like(x)
+        _same_storage(x, y)
         call(_A("vg_bn_apply", x), _p(x), _ptr(mean), _ptr(invstd), _ptr(gamma), _ptr(beta), _p(y), m, c,
              act, c_float(slope), _stream())
         ctx.act, ctx.slope = act, slope
@@ -1112,6 +1115,7 @@ class BatchNormBwdFn(Function):
         m, c = _rows_cols(x)
         mask = _act_args(act, slope)
         sums = torch.empty((2, c), dtype=torch.float32, device=x.device)
+        _same_storage(gy, x)
         if left is not None:          # the kernel that produced gy left the two sums per row tile: add the tiles
             call("vg_bn_bwd_sums_from_conv", left[0], ctypes.byref(left[1].c), ctypes.c_void_p(left[2].data_ptr()),
                  _ptr(sums), _stream())
@@ -1120,6 +1124,7 @@ class BatchNormBwdFn(Function):
             call(_A("vg_bn_bwd_reduce", x), _p(gy), _p(x), _ptr(mean), _ptr(invstd), m, c, _ptr(sums),
                  ctypes.c_void_p(ws.data_ptr()), c_size_t(nbytes), *mask, _ptr(gamma), _ptr(mask_beta), _stream())
         gx = torch.empty_like(x)
+        _same_storage(gy, x, gx)
         call(_A("vg_bn_bwd_apply", x), _p(gy), _p(x), _ptr(mean), _ptr(invstd), _ptr(gamma), _ptr(sums), _p(gx), m, c,
              *mask, _ptr(mask_beta), _stream())
         ctx.set_materialize_grads(False)
@@ -1141,6 +1146,7 @@ class BatchNormBwdFn(Function):
         v = v.contiguous() if v is not None else None
         w = w.contiguous() if w is not None else None
         sums5 = torch.empty((5, c), dtype=torch.float32, device=x.device)
+        _same_storage(gy, x, u)
         ws, nbytes = _bn_ws(m, c, x.device)
         call(_A("vg_bn_dbwd_reduce", x), _p(gy), _p(x), _p(u), _ptr(mean), _ptr(invstd), m, c, _ptr(sums5),
              ctypes.c_void_p(ws.data_ptr()), c_size_t(nbytes), *mask, _ptr(gamma), _ptr(mask_beta), _stream())
@@ -1175,6 +1181,7 @@ class BatchNormEvalFn(Function):
     def backward(ctx, gy):
         x, gamma, beta, mean, invstd, y = ctx.saved_tensors
         gy = _cast_raw(to_nhwc(gy), x.dtype)
+        _same_storage(gy, x, y)
         m, c = _rows_cols(x)
         if y is not None:  # undo the fused activation first: g = gy * act'(y)
             g = torch.empty_like(x)
@@ -1251,6 +1258,7 @@ class ActBwdFn(Function):
         ref = _dense_like(ref)
         gy = _cast_raw(_match_layout(_dense_like(gy), ref), ref.dtype)
         gx = torch.empty_like(ref)
+        _same_storage(gy, ref, gx)
         call(_A("vg_act_bwd", ref), _p(gy), _p(ref), _p(gx), c_size_t(ref.numel()), act, c_float(slope), _stream())
         return gx
 
@@ -1266,6 +1274,7 @@ class ActBwdFn(Function):
             gg_ = _cast_raw(_match_layout(_dense_like(gg), ref_), ref_.dtype)
             gy_ = _cast_raw(_match_layout(_dense_like(gy), ref_), ref_.dtype)
             d_ref = torch.empty_like(ref_)
+            _same_storage(gg_, gy_, ref_, d_ref)
             call(_A("vg_act_dbwd_ref", ref_), _p(gg_), _p(gy_), _p(ref_), _p(d_ref), c_size_t(ref_.numel()), ctx.act,
                  _stream())
         return d_gy, d_ref, None, None
