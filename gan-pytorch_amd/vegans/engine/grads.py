@@ -42,6 +42,22 @@ def collecting():
     return _active is not None
 
 
+# Stream-order primitives of the ledger (host-logic tests replace them with recorders that need no GPU).
+def _needs_events(grad):
+    """Whether contributions of the current backward pass may be produced on several streams (engine/streams.py)."""
+    return grad.is_cuda and streams.forked()
+
+
+def _record_event():
+    ev = torch.cuda.Event()
+    ev.record()
+    return ev
+
+
+def _wait_event(ev):
+    torch.cuda.current_stream().wait_event(ev)
+
+
 def route(param, label, grad):
     """Give `grad` (a contribution to d loss / d param, or None) to the collecting ledger and return None, or return it
     unchanged when no ledger is collecting for `param` (plain autograd use of the operators: autograd then
@@ -121,7 +137,12 @@ class Ledger:
         self.sink = sink
         self.summer = summer if summer is not None else sum_into    # host-logic tests pass a CPU stand-in
         self.done = set()
-        self.events = []     # completion events of contributions produced on side streams
+        # Stream order while the passes of a sub-step run on several streams: a contribution leaves an event under ITS
+        # parameter when it is deposited, the sum of a parameter waits for that parameter's events only (and consumes
+        # them: nobody else needs them), and an early sum (data-parallel sink) leaves an event of its own under the
+        # parameter, which the bucket's all-reduce waits for, whichever stream each of the three ran on.
+        self.events = {}     # id(param) -> [event per contribution produced while side streams are in use]
+        self.summed = {}     # id(param) -> event behind the kernel that wrote its sum into the bucket slot
 
     def __enter__(self):
         global _active
@@ -147,11 +168,9 @@ class Ledger:
             raise _hip.HipError("a gradient contribution arrived after its parameter's bucket had been handed to the "
                                 "all-reduce: the model's backward graph changed between two iterations")
         self.entries.setdefault(key, []).append((label, grad.detach()))
-        if grad.is_cuda and streams.forked():
+        if _needs_events(grad):
             # produced on whatever stream this backward node runs on; the summation waits for it (flush)
-            ev = torch.cuda.Event()
-            ev.record()
-            self.events.append(ev)
+            self.events.setdefault(key, []).append(_record_event())
         if self.sink is not None:
             self.sink.deposited(self, param, len(self.entries[key]))
 
@@ -164,11 +183,11 @@ class Ledger:
         todo = [p for p in params if id(p) not in self.done and id(p) in self.entries]
         if not todo:
             return
-        if self.events:
-            cur = torch.cuda.current_stream()
-            for ev in self.events:
-                cur.wait_event(ev)
-            self.events = []
+        waited = False
+        for p in todo:
+            for ev in self.events.pop(id(p), ()):
+                _wait_event(ev)
+                waited = True
         if self.sink is None:
             outs, scale = [None] * len(todo), 1.0
         else:
@@ -177,6 +196,26 @@ class Ledger:
         for p, s in zip(todo, sums):
             p.grad = s if s.shape == p.shape and s.stride() == p.stride() else s.as_strided(p.shape, p.stride())
             self.done.add(id(p))
+        if self.sink is not None and (waited or (sums and _needs_events(sums[0]))):
+            ev = _record_event()
+            for p in todo:
+                self.summed[id(p)] = ev
+
+    def wait_summed(self, params):
+        """Order the current stream behind the kernels that wrote the sums of `params` (a bucket about to be handed to
+        its collective: its slots may have been written from several streams)."""
+        seen = set()
+        for p in params:
+            ev = self.summed.get(id(p))
+            if ev is not None and id(ev) not in seen:
+                seen.add(id(ev))
+                _wait_event(ev)
+
+    def joined(self):
+        """The launch stream has been ordered behind every side stream of the sub-step (streams.join): whatever is
+        summed or exchanged on it from here on needs no event."""
+        self.events = {}
+        self.summed = {}
 
     def close(self):
         self.flush(self.params)

@@ -97,6 +97,7 @@ class _StepGraph:
         self.grads = None
         self.scratch = None
         self.replays = 0
+        self.verify = False      # data parallel with captured collectives: check the ranks against each other once
 
     def carve(self, shape):
         """A static buffer for a host input. It must not come from the graph's own memory pool: the pool hands a block
@@ -187,6 +188,10 @@ class _StepGraph:
         for p, g in self.grads:
             p.grad = g
         self.replays += 1
+        if self.verify:
+            self.verify = False
+            from . import parallel
+            parallel.verify_replicas(model)
 
 
 _GRAPHABLE_OPTIMIZERS = (torch.optim.RMSprop, torch.optim.SGD, torch.optim.Adam, torch.optim.AdamW)
@@ -220,7 +225,10 @@ def _sharding(model):
 def _eligible(model):
     from . import ops
     dp = getattr(model, "_dp", None)
-    if dp is not None and dp.world > 1 and os.environ.get("VEGANS_HIP_GRAPH_DP", "1") == "0":
+    if dp is not None and dp.world > 1 and (os.environ.get("VEGANS_HIP_GRAPH_DP", "1") == "0"
+                                            or getattr(model, "_needs_eager_dp", False)):
+        # the second reason: the iteration exchanges rows between ranks in the middle of a forward pass
+        # (parallel.gather_rows: the pairwise gradient penalty on vector data)
         return False
     if os.environ.get("VEGANS_HIP_GRAPH", "1") == "0" or ops.conv_timer is not None:
         return False
@@ -256,9 +264,33 @@ def run_step(model, body, inputs):
         if entry.eager_calls < WARM_EAGER_CALLS:
             entry.eager_calls += 1
             return body(*inputs)
+        from . import parallel
+        dp = getattr(model, "_dp", None)
+        sharded = dp is not None and dp.world > 1
+        error = None
         try:
             entry.capture(model, body, inputs)
-        except Exception as exc:  # not capturable: stay eager for this signature
+        except Exception as exc:  # not capturable
+            error = exc
+        if sharded and parallel.collectives_captured():
+            # the graph carries its own all-reduces: every rank must have captured it, or none keeps it
+            if not parallel._agree(error is None):
+                parallel.refuse_captured(error if error is not None else "the capture failed on another rank")
+                for net in model.neural_nets.values():
+                    for p in net.parameters():
+                        p.grad = None
+                torch.cuda.synchronize()
+                entry = cache[key] = _StepGraph()
+                entry.eager_calls = WARM_EAGER_CALLS
+                error = None
+                try:
+                    entry.capture(model, body, inputs)       # second attempt, cut at the gradient exchanges
+                except Exception as exc:
+                    error = exc
+            else:
+                entry.verify = True
+        if error is not None:      # stay eager for this signature
+            exc = error
             entry.failed = True
             entry.graph = None
             for net in model.neural_nets.values():

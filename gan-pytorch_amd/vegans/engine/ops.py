@@ -1536,8 +1536,10 @@ def _penalty_leaf(t):
 def gp_interpolate_pairs(alpha, real, fake):
     """The reference's interpolation for VECTOR data (2-d `real` [B, D]): its alpha has shape [B, 1, 1, 1]
     (WassersteinGANGP.py:68), which broadcasts against [B, D] to [B, 1, B, D]: every alpha is paired with every sample,
-    out[i][j] = alpha[i]*real[j] + (1-alpha[i])*fake[j]. Returned as the [B*B, D] leaf the critic is applied to; the
-    penalty then takes one norm per alpha over all B*D gradient elements of its row block (`gradient_penalty(rows=B)`)."""
+    out[i][j] = alpha[i]*real[j] + (1-alpha[i])*fake[j]. Returned as the [A*B, D] leaf the critic is applied to; the
+    penalty then takes one norm per alpha over all B*D gradient elements of its row block (`gradient_penalty(rows=A)`).
+    A, the number of alphas, is B on one GPU; a data-parallel rank holds the alphas of its rows only and pairs them
+    with the samples of the WHOLE batch (nn.DataParallel scatters the [B, 1, B, D] critic input along its first axis)."""
     real = _dense_like(real.detach())
     fake = _match_layout(_dense_like(fake.detach()), real)
     if real.dim() != 2 or real.shape != fake.shape:
@@ -1545,15 +1547,16 @@ def gp_interpolate_pairs(alpha, real, fake):
                             (tuple(real.shape), tuple(fake.shape)))
     b, d = real.shape
     alpha = alpha.reshape(-1)
-    if alpha.numel() != b or not alpha.is_contiguous():
-        raise _hip.HipError("alpha must hold one value per sample")
+    a = alpha.numel()
+    if a < 1 or not alpha.is_contiguous():
+        raise _hip.HipError("alpha must hold at least one contiguous value")
     _require_gpu(alpha)
-    tiled_real = torch.empty((b, b * d), dtype=torch.float32, device=real.device)
-    tiled_fake = torch.empty((b, b * d), dtype=torch.float32, device=real.device)
-    call("vg_bcast_rows", _ptr(real), _ptr(tiled_real), b, b * d, _stream())
-    call("vg_bcast_rows", _ptr(fake), _ptr(tiled_fake), b, b * d, _stream())
-    out = torch.empty((b * b, d), dtype=torch.float32, device=real.device)
-    call("vg_gp_interp", _ptr(alpha), _ptr(tiled_real), _ptr(tiled_fake), _ptr(out), b, c_size_t(b * d), _stream())
+    tiled_real = torch.empty((a, b * d), dtype=torch.float32, device=real.device)
+    tiled_fake = torch.empty((a, b * d), dtype=torch.float32, device=real.device)
+    call("vg_bcast_rows", _ptr(real), _ptr(tiled_real), a, b * d, _stream())
+    call("vg_bcast_rows", _ptr(fake), _ptr(tiled_fake), a, b * d, _stream())
+    out = torch.empty((a * b, d), dtype=torch.float32, device=real.device)
+    call("vg_gp_interp", _ptr(alpha), _ptr(tiled_real), _ptr(tiled_fake), _ptr(out), a, c_size_t(b * d), _stream())
     return _penalty_leaf(out)
 
 

@@ -78,6 +78,7 @@ def context(model):
                 "uninitialised and let fit() start the workers itself." % (ngpu, ngpu))
         ctx = _Sharded(dist.get_world_size(), dist.get_rank())
         model._dp = ctx
+        probe_captured_collectives()
         for name, net in model.neural_nets.items():
             if not hasattr(net, "_vg_reducer"):
                 net._vg_reducer = GradReducer(list(net.parameters()))
@@ -159,9 +160,9 @@ class GradReducer:
         if _cut_for_collectives() or self.counts is None or self.counts.get(id(p)) != n_so_far:
             return
         ledger.flush([p])
-        self._completed(p)
+        self._completed(p, ledger)
 
-    def _completed(self, p):
+    def _completed(self, p, ledger):
         bi, _ = self.where[id(p)]
         self.touched[bi] = True
         self.pending[bi] -= 1
@@ -170,6 +171,9 @@ class GradReducer:
         # collectives in different orders pair up the wrong buffers.
         while self.next < len(self.buckets) and self.pending[self.next] == 0 and not _cut_for_collectives():
             self.launched[self.next] = True
+            # the slots of this bucket were written by sum kernels on whatever stream each parameter completed on; the
+            # collective is issued from the stream of the LAST one and must be ordered behind all of them
+            ledger.wait_summed(self.buckets[self.next])
             self.works.append(_all_reduce_async(self.flat[self.next]))
             self.next += 1
 
@@ -210,18 +214,116 @@ def _gloo():
     return dist.get_backend() == "gloo"
 
 
+_captured_refused = None     # why this process does not capture its collectives (None: it does, or has not tried yet)
+_probed = False
+
+
+def collectives_captured():
+    """Whether a captured iteration carries its gradient all-reduces INSIDE the HIP graph. Captured, a bucket's
+    all-reduce is a branch of the graph on RCCL's stream that starts as soon as the bucket's last gradient exists and
+    runs beside the rest of the backward pass, in replayed iterations as in eager ones. That needs a communication
+    library that can be stream-captured: RCCL, the default; not gloo, whose collectives run on the host. Otherwise the
+    capture is cut at every gradient exchange and the collectives run between two graph launches as blocking
+    stream-ordered calls (a chain graph | all-reduce | graph ...: no overlap). VEGANS_DP_CAPTURE_COLLECTIVES=0 forces the
+    chain; a failed first contact (probe_captured_collectives, or a capture that raises) selects it for the rest of the
+    process, on all ranks together."""
+    if _gloo() or os.environ.get("VEGANS_DP_CAPTURE_COLLECTIVES", "1") == "0":
+        return False
+    return _captured_refused is None
+
+
+def refuse_captured(reason):
+    global _captured_refused
+    if _captured_refused is None:
+        _captured_refused = str(reason)
+        import warnings
+        warnings.warn("gradient all-reduces will not be captured into the HIP graph (%s): replayed iterations run as a "
+                      "chain graph | all-reduce | graph without overlap" % reason)
+
+
+def overlap_mode(model=None):
+    """How a steady-state data-parallel iteration exchanges gradients: "captured" (all-reduces inside the replayed
+    graph, overlapping backward), "chain" (between graph launches, no overlap), "eager" (no graph: bucket all-reduces
+    start during backward from the host)."""
+    if os.environ.get("VEGANS_HIP_GRAPH", "1") == "0" or os.environ.get("VEGANS_HIP_GRAPH_DP", "1") == "0":
+        return "eager"
+    if model is not None and (getattr(model, "_needs_eager_dp", False) or not getattr(model, "use_step_graph", True)):
+        return "eager"
+    return "captured" if collectives_captured() else "chain"
+
+
+def _agree(ok):
+    """True when `ok` holds on every rank (an eager all-reduce: every rank takes the same branch afterwards)."""
+    flag = torch.tensor([1.0 if ok else 0.0], device="cuda" if dist.get_backend() == "nccl" else "cpu")
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    return bool(flag.item() > 0.5)
+
+
+def probe_captured_collectives():
+    """First contact with stream-captured collectives, once per process, before any training graph depends on them: a
+    HIP graph holding one all-reduce of known values (rank + 1 in every element) is captured and replayed three times
+    on fresh inputs, and the results are checked against world * (world + 1) / 2. Any exception or wrong value, on any
+    rank, makes ALL ranks fall back to the chain."""
+    global _probed
+    if _probed or not _dist_on() or not collectives_captured():
+        return
+    _probed = True
+    world, rank = dist.get_world_size(), dist.get_rank()
+    ok, why = True, ""
+    try:
+        buf = torch.zeros(4096, device="cuda")
+        side = torch.cuda.Stream()
+        dist.all_reduce(buf)                                  # communicator set-up happens outside the capture
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            g.capture_begin(capture_error_mode="thread_local")
+            try:
+                work = dist.all_reduce(buf, op=dist.ReduceOp.SUM, async_op=True)
+                work.wait()
+            finally:
+                g.capture_end()
+        torch.cuda.current_stream().wait_stream(side)
+        for k in range(3):
+            buf.fill_(float(rank + 1 + k))
+            g.replay()
+            torch.cuda.synchronize()
+            want = world * (world + 1) / 2.0 + k * world
+            if not bool((buf == want).all()):
+                ok, why = False, "a replayed all-reduce returned %r instead of %r" % (float(buf[0]), want)
+                break
+    except Exception as exc:   # noqa: BLE001 - whatever the communication library or the capture raises
+        ok, why = False, "%s: %s" % (type(exc).__name__, exc)
+    if not _agree(ok):
+        refuse_captured(why or "another rank's probe of captured collectives failed")
+
+
 def _cut_for_collectives():
-    """While an iteration is being captured: whether the capture is cut at every gradient exchange (the collectives then
-    run between two graph launches, as blocking stream-ordered calls) or the collectives are captured with everything
-    else. Captured, a bucket's all-reduce is a branch of the graph on RCCL's stream that starts as soon as the bucket's
-    last gradient exists and runs beside the rest of the backward pass, also in replayed iterations; that needs a
-    communication library that can be stream-captured (RCCL; not gloo, whose collectives run on the host).
-    VEGANS_DP_CAPTURE_COLLECTIVES=1 selects it, the default is the cut."""
+    """While an iteration is being captured: whether the capture is cut at every gradient exchange (see
+    collectives_captured)."""
     if not graph.capturing():
         return False
-    if _gloo():
-        return True
-    return os.environ.get("VEGANS_DP_CAPTURE_COLLECTIVES", "0") != "1"
+    return not collectives_captured()
+
+
+def verify_replicas(model):
+    """After the first replay of a graph that carries its own collectives: the reduced gradient buckets must hold the
+    same bits on every rank (an all-reduce hands every rank the same sum). One MAX and one MIN all-reduce per network,
+    once per captured graph; a difference means the captured collectives did not exchange what the eager ones do and is
+    raised, not papered over."""
+    if not _dist_on():
+        return
+    for name, net in model.neural_nets.items():
+        red = getattr(net, "_vg_reducer", None)
+        if red is None:
+            continue
+        hi, lo = red.whole.clone(), red.whole.clone()
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        if not torch.equal(hi, lo):
+            raise RuntimeError("data-parallel replicas disagree on the reduced gradients of %s after the first replayed "
+                               "iteration with captured collectives; set VEGANS_DP_CAPTURE_COLLECTIVES=0" % name)
 
 
 def _all_reduce_async(flat):
@@ -280,6 +382,38 @@ def reduce_logged(model, losses):
         fake = values.get("Adversariat_fake")
         values["RealFakeRatio"] = values["Adversariat_real"] / fake if fake else float("nan")
     return values
+
+
+def gather_rows(model, local):
+    """The row shards of all ranks of a [rows, D] device tensor, concatenated in rank order: the whole batch, on every
+    rank. No gradient flows through (the callers gather data and detached samples). Shards may differ in size
+    (`chunk_bounds`); they travel padded to the largest. The exchange is an eager collective in the middle of a forward
+    pass, so a model that needs it stays out of HIP-graph capture under data parallelism (`_needs_eager_dp`)."""
+    ctx = getattr(model, "_dp", None)
+    if ctx is None or ctx.world == 1 or not _dist_on():
+        return local
+    model._needs_eager_dp = True
+    if graph.capturing():
+        raise RuntimeError("a row gather was reached while the iteration was being captured")
+    local = local.detach()
+    size = (ctx.global_rows + ctx.world - 1) // ctx.world
+    if local.shape[0] != ctx.local_rows:
+        raise RuntimeError("gather_rows: %d rows, but this rank's shard has %d" % (local.shape[0], ctx.local_rows))
+    padded = local.new_zeros((size,) + tuple(local.shape[1:]))
+    padded[:local.shape[0]].copy_(local)
+    if _gloo() and padded.is_cuda:
+        host = padded.cpu()
+        pieces = [torch.empty_like(host) for _ in range(ctx.world)]
+        dist.all_gather(pieces, host)
+        pieces = [t.to(local.device) for t in pieces]
+    else:
+        pieces = [torch.empty_like(padded) for _ in range(ctx.world)]
+        dist.all_gather(pieces, padded)
+    rows = []
+    for rank, t in enumerate(pieces):
+        lo, hi = chunk_bounds(ctx.global_rows, ctx.world, rank)
+        rows.append(t[:hi - lo])
+    return torch.cat(rows, dim=0)
 
 
 def open_ledger(model, who):

@@ -6,8 +6,11 @@ process group, `fit` starts those processes itself:
 
   parent   writes the model object (torch.save), the training arrays, the fit() arguments and the three random
            generator states to a scratch directory and starts N fresh Python processes (`python -m
-           vegans.engine.spawn <dir> <rank> <world> <port>`; new interpreters, never a re-exec of this process);
-  worker r selects GPU r, joins the process group (RCCL; VEGANS_DP_BACKEND=gloo for rehearsals), loads the model onto its
+           vegans.engine.spawn <dir> <rank> <world> <backend>`; new interpreters, never a re-exec of this process),
+           then watches all of them: the first worker that exits with an error ends the others (they would otherwise
+           sit in a collective until the communication library's timeout) and its log becomes the exception text;
+  worker r selects GPU r, joins the process group through a file in the scratch directory (RCCL;
+           VEGANS_DP_BACKEND=gloo for rehearsals), loads the model onto its
            GPU, restores the generator states (so every rank draws the same latent batches and penalty alphas and
            keeps its rows) and calls the ordinary `fit`, which shards every batch;
   rank 0   writes parameters, BatchNorm buffers, optimizer state, logged losses, hyper-parameters and the advanced
@@ -16,10 +19,10 @@ process group, `fit` starts those processes itself:
 import os
 import pickle
 import shutil
-import socket
 import subprocess
 import sys
 import tempfile
+import time
 
 import numpy as np
 import torch
@@ -27,10 +30,42 @@ import torch
 _ARRAYS = ("X_train", "y_train", "X_test", "y_test")
 
 
-def _free_port():
-    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
-        s.bind(("127.0.0.1", 0))
-        return s.getsockname()[1]
+POLL_SECONDS = 0.2
+_sleep = time.sleep
+
+
+def _stop(procs, grace=5.0):
+    """End every worker that is still running: SIGTERM, then SIGKILL after `grace` seconds."""
+    alive = [p for p in procs if p.poll() is None]
+    for p in alive:
+        p.terminate()
+    deadline = time.monotonic() + grace
+    for p in alive:
+        try:
+            p.wait(timeout=max(deadline - time.monotonic(), 0.1))
+        except subprocess.TimeoutExpired:
+            p.kill()
+            p.wait()
+
+
+def wait_all(procs):
+    """Wait for all `procs` (subprocess.Popen) together. Returns None when every one exited with status 0; as soon as
+    one exits with another status the rest are stopped and (index, status) of that first failure is returned. Whatever
+    ends the wait (an exception in the caller's thread, KeyboardInterrupt), no worker is left running."""
+    try:
+        while True:
+            running = False
+            for i, p in enumerate(procs):
+                rc = p.poll()
+                if rc is None:
+                    running = True
+                elif rc != 0:
+                    return i, rc
+            if not running:
+                return None
+            _sleep(POLL_SECONDS)
+    finally:
+        _stop(procs)
 
 
 def fit_in_workers(model, fit_kwargs):
@@ -54,25 +89,24 @@ def fit_in_workers(model, fit_kwargs):
                  "numpy": np.random.get_state(), "class": type(model).__name__}
         with open(os.path.join(work, "call.pkl"), "wb") as f:
             pickle.dump(state, f)
-        port = _free_port()
         env = dict(os.environ)
         env["PYTHONPATH"] = os.pathsep.join([p for p in sys.path if p] + [env.get("PYTHONPATH", "")])
-        env["MASTER_ADDR"], env["MASTER_PORT"] = "127.0.0.1", str(port)
-        procs = []
-        for rank in range(world):
-            log = open(os.path.join(work, "rank%d.log" % rank), "wb")
-            procs.append((subprocess.Popen([sys.executable, "-m", "vegans.engine.spawn", work, str(rank), str(world),
-                                            backend], env=env, stdout=log, stderr=subprocess.STDOUT), log))
-        failed = []
-        for rank, (proc, log) in enumerate(procs):
-            rc = proc.wait()
-            log.close()
-            if rc != 0:
-                failed.append((rank, rc))
-        if failed:
-            rank, rc = failed[0]
+        procs, logs = [], []
+        try:
+            for rank in range(world):
+                logs.append(open(os.path.join(work, "rank%d.log" % rank), "wb"))
+                procs.append(subprocess.Popen([sys.executable, "-m", "vegans.engine.spawn", work, str(rank), str(world),
+                                               backend], env=env, stdout=logs[-1], stderr=subprocess.STDOUT))
+            failed = wait_all(procs)
+        finally:
+            _stop(procs)
+            for log in logs:
+                log.close()
+        if failed is not None:
+            rank, rc = failed
             tail = open(os.path.join(work, "rank%d.log" % rank), "rb").read()[-4000:].decode(errors="replace")
-            raise RuntimeError("data-parallel worker %d of %d exited with status %d:\n%s" % (rank, world, rc, tail))
+            raise RuntimeError("data-parallel worker %d of %d exited with status %d (the other workers were stopped):\n%s"
+                               % (rank, world, rc, tail))
         sys.stdout.write(open(os.path.join(work, "rank0.log"), "rb").read().decode(errors="replace"))
         result = torch.load(os.path.join(work, "result.pt"), weights_only=False, map_location="cuda")
     finally:
@@ -104,10 +138,13 @@ def _worker(work, rank, world, backend):
         raise RuntimeError("worker %d sees no GPU" % rank)
     device = rank % ndev           # more ranks than GPUs only happens in gloo rehearsals on a one-GPU box
     torch.cuda.set_device(device)
+    # rendezvous through a file of the scratch directory: no TCP port that another process could take in between
+    rendezvous = "file://" + os.path.join(work, "rendezvous")
     if backend == "nccl":
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", device))
+        dist.init_process_group("nccl", init_method=rendezvous, rank=rank, world_size=world,
+                                device_id=torch.device("cuda", device))
     else:
-        dist.init_process_group(backend, rank=rank, world_size=world)
+        dist.init_process_group(backend, init_method=rendezvous, rank=rank, world_size=world)
     with open(os.path.join(work, "call.pkl"), "rb") as f:
         state = pickle.load(f)
     model = torch.load(os.path.join(work, "model.pt"), weights_only=False, map_location=torch.device("cuda", device))

@@ -413,8 +413,8 @@ class AbstractGenerativeModel(ABC):
                         loss.backward(gradient=seed, retain_graph=True)
             # backward nodes ran on the streams of their forward passes (engine/streams.py); order the launch stream
             # behind all of them before the ledger adds up what they produced
-            ledger.events = []
             streams.join(after_backward=True)
+            ledger.joined()
 
     def _step(self, who=None, clamp=None):
         names = [who] if who is not None else list(self.optimizers)

@@ -14,7 +14,7 @@ kernels as constants; no target tensors are materialised and nothing is read bac
 import numpy as np
 import torch
 
-from ..engine import graph, ops, streams
+from ..engine import graph, ops, parallel, streams
 from ..utils import utils
 from ..utils.networks import Adversariat, Generator
 from .base import AbstractConditionalGenerativeModel, AbstractGenerativeModel, resolve_device
@@ -143,7 +143,11 @@ class _PenaltyMixin:
         if real_images.dim() == 2:
             # vector data: the reference's [B,1,1,1] alpha broadcasts against [B,D] to all B x B (alpha, sample)
             # pairs, and its norm runs over the B*D gradient elements that belong to one alpha
-            # (WassersteinGANGP.py:68-69,80-81)
+            # (WassersteinGANGP.py:68-69,80-81). Under data parallelism a rank holds the alphas of its rows and pairs
+            # them with the samples of the WHOLE batch, as nn.DataParallel does when it scatters the [B, 1, B, D]
+            # critic input along its first axis: the other ranks' rows are gathered (no gradient flows into them)
+            real_images = parallel.gather_rows(self, real_images)
+            fake_images = parallel.gather_rows(self, fake_images)
             interpolates = ops.gp_interpolate_pairs(alpha, real_images, fake_images)
         else:
             interpolates = ops.gp_interpolate(alpha, real_images, fake_images)

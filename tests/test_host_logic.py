@@ -232,6 +232,114 @@ def test_ledger_sums_in_label_order_on_cpu():
     assert a < b and a + (0,) < b
 
 
+def test_ledger_orders_sums_and_collectives_across_streams(monkeypatch):
+    """Parameters that complete on alternating streams (the critic's fake / real / penalty chains run their backward
+    nodes on three streams): the sum of a parameter must wait for the contributions of THAT parameter from every stream
+    and must not consume another parameter's events; the all-reduce of a bucket must wait for the sum kernels of every
+    parameter in it, whichever streams they ran on. Streams and events are recorders here (no GPU): a stream is a name,
+    an event remembers where it was recorded, a wait is logged as (waiting stream, event)."""
+    from vegans.engine import grads, parallel
+    now = {"stream": "main"}
+    log = []
+
+    class Ev:
+        def __init__(self, what):
+            self.stream, self.what = now["stream"], what
+
+    monkeypatch.setattr(grads, "_needs_events", lambda grad: True)
+    monkeypatch.setattr(grads, "_record_event", lambda: Ev(len(log)))
+    monkeypatch.setattr(grads, "_wait_event", lambda ev: log.append(("wait", now["stream"], ev)))
+    reduced = []
+    monkeypatch.setattr(parallel, "_all_reduce_async", lambda flat: (log.append(("reduce", now["stream"], flat)),
+                                                                     reduced.append(flat))[1])
+    monkeypatch.setattr(parallel, "_cut_for_collectives", lambda: False)
+
+    params = [torch.nn.Parameter(torch.zeros(4)) for _ in range(4)]
+    sums = []
+
+    def summer(items, scale):
+        out = []
+        for p, sources, dst in items:
+            acc = sources[0].clone()
+            for t in sources[1:]:
+                acc = acc + t
+            dst.copy_(acc * scale)
+            sums.append((now["stream"], id(p), len(log)))
+            out.append(dst)
+        return out
+
+    red = parallel.GradReducer(params, n_buckets=2, summer=summer)
+    assert len(red.buckets) == 2 and [len(b) for b in red.buckets] == [2, 2]
+    order = [p for b in red.buckets for p in b]           # bucket 0: order[0], order[1]; bucket 1: order[2], order[3]
+    streams_of = {id(order[0]): ("side0", "main"), id(order[1]): ("side1", "side0"),
+                  id(order[2]): ("main", "side1"), id(order[3]): ("side0", "side1")}
+
+    def backward_pass():
+        # two contributions per parameter, from different streams; a parameter completes on its second contribution
+        for p in params:
+            p.grad = None
+        with red.open(1.0) as ledger:
+            for k in (0, 1):
+                for p in order:
+                    now["stream"] = streams_of[id(p)][k]
+                    grads.route(p, (k + 1,), torch.full((4,), float(k + 1)))
+            now["stream"] = "main"
+            ledger.joined()
+        red.finish()
+
+    backward_pass()                 # first pass: contribution counts unknown, everything summed at the end on "main"
+    assert all(s == "main" for s, _, _ in sums)
+    del log[:], sums[:], reduced[:]
+    backward_pass()                 # second pass: early sums on the completing stream, buckets reduced as they fill
+    assert [s for s, _, _ in sums] == [streams_of[id(p)][1] for p in order]
+    for p in order:
+        first, second = streams_of[id(p)]
+        at = next(i for s, key, i in sums if key == id(p))
+        waited = [ev for kind, stream, ev in log[:at] if kind == "wait" and stream == second]
+        # the sum, launched on `second`, is ordered behind the parameter's contribution from `first`
+        assert any(ev.stream == first for ev in waited), (first, second)
+    # every bucket's collective is ordered behind the sum kernels of both its parameters
+    for bi, bucket in enumerate(red.buckets):
+        at = next(i for i, row in enumerate(log) if row[0] == "reduce" and row[2] is red.flat[bi])
+        stream = log[at][1]
+        behind = {ev.stream for kind, s, ev in log[:at] if kind == "wait" and s == stream}
+        for p in bucket:
+            done_on = streams_of[id(p)][1]
+            assert done_on == stream or done_on in behind, (bi, done_on, stream, behind)
+    assert len(reduced) == 2
+    for p in order:
+        assert torch.equal(p.grad, torch.full((4,), 3.0))
+
+
+def test_worker_supervision_stops_siblings_on_first_failure():
+    """fit()'s worker supervision (engine/spawn.py): one worker dies, the other would wait in a collective for the
+    communication library's timeout; the parent must notice at once, stop the survivor and report the dead one."""
+    import time
+    from vegans.engine import spawn
+    sleeper = subprocess.Popen([sys.executable, "-c", "import time; time.sleep(120)"])
+    dying = subprocess.Popen([sys.executable, "-c", "import sys, time; time.sleep(0.3); sys.exit(3)"])
+    t0 = time.monotonic()
+    assert spawn.wait_all([sleeper, dying]) == (1, 3)
+    assert time.monotonic() - t0 < 30
+    assert sleeper.poll() is not None and dying.poll() == 3          # nobody left running
+    ok = [subprocess.Popen([sys.executable, "-c", "pass"]) for _ in range(2)]
+    assert spawn.wait_all(ok) is None
+    # an interrupt in the parent while it waits leaves no worker behind either
+    sleeper = subprocess.Popen([sys.executable, "-c", "import time; time.sleep(120)"])
+    plain_sleep = spawn._sleep
+
+    def interrupted(_):
+        raise KeyboardInterrupt
+
+    spawn._sleep = interrupted
+    try:
+        with pytest.raises(KeyboardInterrupt):
+            spawn.wait_all([sleeper])
+    finally:
+        spawn._sleep = plain_sleep
+    assert sleeper.poll() is not None
+
+
 def test_grad_reducer_two_ranks_gloo(tmp_path):
     script = tmp_path / "worker.py"
     script.write_text(_WORKER % {"root": ROOT})

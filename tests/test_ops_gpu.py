@@ -42,6 +42,13 @@ CONV_CASES = [
     (5, 1, 21, 70, 64, 4, 2, 1),     # stem kernel, Ci=1, several column tiles with a ragged last one
     (6, 3, 11, 9, 128, 3, 1, 1),     # stem weight-gradient kernel: odd K = 27, two channel tiles, ragged pixel tiles
     (3, 1, 30, 30, 64, 5, 2, 2),     # stem weight-gradient kernel: Ci=1, 5x5 stride 2, more slabs than tiles
+    # the benchmark's own launches: DCGAN-64 critic layers at batch 256 (the split-K plan, grid sizes and slab set of
+    # that batch; the other cases run at a few images)
+    (256, 3, 64, 64, 64, 4, 2, 1),   # image stem: 262144 output pixels
+    (256, 64, 32, 32, 128, 4, 2, 1),  # fat layer 1: M = 65536, K = 1024
+    (256, 128, 16, 16, 256, 4, 2, 1),  # fat layer 2: M = 16384, K = 2048
+    (256, 256, 8, 8, 512, 4, 2, 1),   # fat layer 3: M = 4096, K = 4096
+    (256, 512, 4, 4, 1, 4, 1, 0),     # critic head
 ]
 
 
@@ -211,6 +218,12 @@ CONVT_CASES = [
     (2, 16, 8, 8, 3, 4, 2, 1),      # image head, Cout=3
     (3, 8, 5, 7, 12, 3, 1, 1),      # stride 1
     (2, 20, 4, 4, 10, 5, 3, 1),     # stride 3, k=5: parity classes with different tap counts
+    # the benchmark's own launches: DCGAN-64 generator layers at batch 256
+    (256, 100, 1, 1, 512, 4, 1, 0),   # latent GEMM
+    (256, 512, 4, 4, 256, 4, 2, 1),   # 4 classes x (4096 x 256 x 2048)
+    (256, 256, 8, 8, 128, 4, 2, 1),   # 4 classes x (16384 x 128 x 1024)
+    (256, 128, 16, 16, 64, 4, 2, 1),  # 4 classes x (65536 x 64 x 512): the short-k, 64-column kernel
+    (256, 64, 32, 32, 3, 4, 2, 1),    # image tail: scatter form
 ]
 
 
@@ -818,6 +831,13 @@ def test_bn_backward_mask_rebuilt_from_input_equals_mask_from_output(gpu, act, s
     ("convT", (16, 25, 24, 64, 64, 4, 2, 1), True),       # transposed, 128 x 64 tiles, ragged last tile of every class
     ("convT", (3, 5, 7, 64, 64, 4, 2, 1), False),         # transposed, too small for the eight-wave tiles
     ("convT", (40, 16, 16, 128, 128, 3, 1, 1), True),     # transposed, stride 1: a single class
+    # batch 256, the DCGAN-64 layers in front of a BatchNorm: up to 2048 per-tile records merged per layer
+    ("conv", (256, 32, 32, 64, 128, 4, 2, 1), True),
+    ("conv", (256, 16, 16, 128, 256, 4, 2, 1), True),
+    ("conv", (256, 8, 8, 256, 512, 4, 2, 1), True),
+    ("convT", (256, 4, 4, 512, 256, 4, 2, 1), True),
+    ("convT", (256, 8, 8, 256, 128, 4, 2, 1), True),
+    ("convT", (256, 16, 16, 128, 64, 4, 2, 1), True),
 ])
 def test_batch_statistics_from_the_convolution_epilogue(gpu, kind, shape, served_by_epilogue):
     """A (transposed) convolution followed by a training-mode BatchNorm inside a Sequential: the norm takes its batch
@@ -872,6 +892,12 @@ def test_batch_statistics_from_the_convolution_epilogue(gpu, kind, shape, served
     ("convT", (64, 16, 16, 128, 64, 4, 2, 1), "relu", True),      # input gradient of a transposed convolution
     ("convT", (7, 11, 9, 128, 32, 4, 2, 1), "relu", True),        # ragged
     ("convT", (32, 8, 8, 256, 128, 3, 1, 1), "lrelu", True),      # stride 1
+    # batch 256, the DCGAN-64 norms and the layer behind each
+    ("conv", (256, 16, 16, 128, 256, 4, 2, 1), "lrelu", True),
+    ("conv", (256, 8, 8, 256, 512, 4, 2, 1), "lrelu", True),
+    ("convT", (256, 4, 4, 512, 256, 4, 2, 1), "relu", True),
+    ("convT", (256, 8, 8, 256, 128, 4, 2, 1), "relu", True),
+    ("convT", (256, 16, 16, 128, 64, 4, 2, 1), "relu", True),
 ])
 def test_norm_backward_sums_from_the_convolution_epilogue(gpu, kind, shape, act, served_by_epilogue):
     """BatchNorm (+ activation) in front of a (transposed) convolution: in the backward pass the kernel that produces
@@ -973,6 +999,9 @@ def test_norm_backward_sums_are_not_taken_when_the_gradient_was_summed(gpu):
     # two pairs in a row, ragged tiles, a norm behind the last convolution
     (lambda nn: [nn.Conv2d(3, 64, 4, 2, 1), nn.LeakyReLU(0.2), nn.Conv2d(64, 128, 3, 1, 1), nn.ReLU(),
                  nn.Conv2d(128, 64, 4, 2, 1, bias=False), nn.BatchNorm2d(64), nn.LeakyReLU(0.2)], (9, 3, 26, 22)),
+    # batch 256: the DCGAN-64 critic's stem, its LeakyReLU and the first fat layer
+    (lambda nn: [nn.Conv2d(3, 64, 4, 2, 1, bias=False), nn.LeakyReLU(0.2), nn.Conv2d(64, 128, 4, 2, 1, bias=False)],
+     (256, 3, 64, 64)),
 ])
 def test_activation_gradient_carried_by_the_next_convolutions_input_gradient(gpu, layers, in_shape):
     """conv -> ReLU / LeakyReLU -> conv inside a Sequential: the second convolution's backward returns its input

@@ -65,6 +65,44 @@ print("rank %%d worst_rel %%.3e identical_across_ranks %%s" %% (rank, worst, sam
 assert same, "ranks diverged"
 assert worst < 2e-4, worst
 
+# ---- vector data: the penalty pairs every alpha with every sample of the WHOLE batch ----------------------------------
+# (WassersteinGANGP.py:68-69: a [B,1,1,1] alpha against [B,D] samples; nn.DataParallel scatters the [B,1,B,D] critic
+# input along its first axis, so a replica holds its alphas and all B samples.) The networks have no BatchNorm, so the
+# two-rank run must equal the single-process run on whole batches, which a reference fixture pins (wgangp_vec).
+def vec_nets():
+    G = nn.Sequential(nn.Linear(8, 32), nn.LeakyReLU(0.2), nn.Linear(32, 20), nn.Tanh())
+    D = nn.Sequential(nn.Linear(20, 32), nn.LeakyReLU(0.2), nn.Linear(32, 16), nn.LeakyReLU(0.2), nn.Linear(16, 1),
+                      nn.Identity())
+    return cfg.seeded_init(G, 1), cfg.seeded_init(D, 2)
+
+def run_vec(ngpu, rows):
+    torch.manual_seed(5); np.random.seed(5)
+    G, D = vec_nets()
+    with contextlib.redirect_stdout(io.StringIO()):
+        m = gan.WassersteinGANGP(G, D, x_dim=(20,), z_dim=(8,), folder=None, fixed_noise_size=2, ngpu=ngpu,
+                                 optim_kwargs={"Generator": {"lr": 1e-3}, "Adversariat": {"lr": 5e-4}})
+    X = cfg.synthetic_images(rows * 5 - 3, (20,), seed=3)             # last batch is partial (uneven shards)
+    zgen = torch.Generator().manual_seed(11)
+    zs = iter([torch.randn(rows, 8, generator=zgen) for _ in range(5)])
+    m.sample = lambda n: next(zs)[:n].to("cuda").requires_grad_(True)
+    np.random.seed(17)
+    with contextlib.redirect_stdout(io.StringIO()):
+        m.fit(X, epochs=1, batch_size=rows, print_every=None, save_losses_every=2, enable_tensorboard=False)
+    from vegans.engine import graph
+    if ngpu:       # the row gather in the middle of the forward pass keeps data-parallel iterations out of graph capture
+        assert not [e for e in graph._graphs.get(m, {}).values() if e.graph is not None]
+    return [p.detach().cpu().clone() for net in (G, D) for p in net.parameters()], m.get_losses()["Train"]
+
+dpv, dpl = run_vec(world, 7)
+refv, refl = run_vec(None, 7)
+worst = max(float((a - b).abs().max() / b.abs().max().clamp_min(1e-3)) for a, b in zip(dpv, refv))
+print("rank %%d vector data, pairwise penalty, two ranks vs one process: worst_rel %%.3e" %% (rank, worst))
+assert worst < 2e-4, worst
+for k in refl:
+    if k != "RealFakeRatio":
+        for a, b in zip(dpl[k], refl[k]):
+            assert abs(a - b) <= 1e-4 * max(abs(b), 1e-1), (k, a, b)
+
 # ---- BatchNorm networks against the oracle's two-device emulation ------------------------------------------------
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import copy
