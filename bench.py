@@ -9,13 +9,19 @@ latent draw, the G sub-step and the D sub-step with gradient penalty.  `value` i
 on a numpy array (logging off): W warm-up batches in one `fit` call, then a second `fit` call over exactly K batches
 inside the clock.  The same K iterations on batches already resident in HBM with pre-drawn latents are reported beside
 it (`resident_batches`).  Both timed regions must have replayed the captured HIP graph K times (asserted).
-With N > 1 (launched by torch.distributed.run, one rank per GPU) the global batch is 256*N (weak scaling), sharded
-by rows, with bucketed RCCL all-reduce of the gradients.
+With N > 1 the global batch is 256*N (weak scaling), sharded by rows, one rank per GPU, with bucketed RCCL all-reduce
+of the gradients; the ranks come from `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...`, or,
+when bench.py is started from a plain shell (no WORLD_SIZE in the environment), from this process itself, which then
+starts that launcher as a child before anything has touched the GPU and passes the ranks' output through.
+`config.overlap` says how the steady state exchanged gradients: "captured" (all-reduces inside the replayed HIP graph,
+overlapping backward), "chain" (between graph launches), "eager".
 
 Prints ONE JSON line on rank 0: metric/value (whole-job images/s), plus
   roofline     — achieved TFLOP/s of the dominant convolution kernel (largest total duration): algorithmic conv FLOPs
                  of its launches divided by their HIP-event-timed durations, against the fp32 MFMA peak. The events
                  are taken in eager iterations run right after the timed region (which replays a HIP graph);
+  hbm_kernels  — achieved HBM GB/s of the normalisation / activation / penalty / optimizer kernels against the 8 TB/s
+                 peak, from the newest committed rocprofv3 counter passes of this benchmark;
   cpu_baseline — the CPU oracle (oracle/restated.py, stock torch CPU kernels) timed on the host cores on a bounded
                  sample of the same workload (rank 0, N = 1 only).
 """
@@ -69,20 +75,65 @@ def cpu_baseline(iterations=2, warmup=1):
     oracle.fit(X[BATCH_PER_GPU * warmup:], None, epochs=1, batch_size=BATCH_PER_GPU)
     dt = time.perf_counter() - t0
     return {"value": round(BATCH_PER_GPU * iterations / dt, 2), "unit": "images/s", "cores": torch.get_num_threads(),
-            "kind": "port",
+            "os_cpu_count": os.cpu_count(), "kind": "port",
             "sample": "%d WGAN-GP iterations of batch %d (DCGAN-64, fp32) after %d warm-up, oracle/restated.py on torch "
                       "CPU kernels" % (iterations, BATCH_PER_GPU, warmup)}
 
 
-def measured_traffic(kernel):
-    """HBM bytes per launch of `kernel` from the newest committed PMC summary (profiles/*_pmc_summary.json, written by
-    tools/pmc_summary.py from rocprofv3 FETCH_SIZE / WRITE_SIZE runs of this benchmark), or None."""
+HBM_PEAK_GBPS = 8000.0             # MI355X HBM3E
+
+
+def newest_pmc_summary():
+    """(path, kernels) of the newest committed counter summary of the fp32 benchmark (profiles/round<N>_*_pmc_summary.json,
+    written by tools/pmc_summary.py from rocprofv3 FETCH_SIZE / WRITE_SIZE runs of this benchmark): highest round
+    number first, then the latest modification time; (None, {}) when there is none."""
     import glob
-    found = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_summary.json")))
-    try:
-        kernels = json.load(open(found[-1]))["kernels"]
-    except (IndexError, OSError, ValueError, KeyError):
-        return None
+    import re
+
+    def age(path):
+        m = re.match(r"round(\d+)_", os.path.basename(path))
+        return (int(m.group(1)) if m else -1, os.path.getmtime(path))
+
+    found = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_summary.json")), key=age)
+    for path in reversed(found):
+        try:
+            return path, json.load(open(path))["kernels"]
+        except (OSError, ValueError, KeyError):
+            continue
+    return None, {}
+
+
+# the bandwidth-bound kernels of an iteration whose achieved HBM rate the line reports against the chip's peak
+HBM_KERNELS = ("bn_apply_kernel", "bn_bwd_apply_kernel", "bn_dbwd_apply_kernel", "act_bwd_kernel", "colreduce_partial",
+               "gp_interp_kernel", "gp_rownorm_kernel", "gp_penalty_bwd_kernel", "rmsprop_multi_kernel",
+               "grad_sum_multi_kernel", "slab_reduce_kernel", "dgrad_scatter_kernel", "stem_fwd_kernel",
+               "stem_wgrad_kernel")
+
+
+def hbm_kernels():
+    """Achieved HBM GB/s of the elementwise, normalisation, penalty and optimizer kernels from the newest committed
+    counter passes (bytes from FETCH_SIZE / WRITE_SIZE, duration from the kernel trace of the same run), each against
+    the 8 TB/s peak."""
+    path, kernels = newest_pmc_summary()
+    rows = []
+    for name, entry in kernels.items():
+        if entry.get("gbps") is None:
+            continue
+        short = name.split("(anonymous namespace)::")[-1].split("(")[0]
+        if any(k in short for k in HBM_KERNELS):
+            if "<" in short and "(anonymous namespace)::" in name.split("<", 1)[1]:
+                inner = name.split("<", 1)[1].split("(anonymous namespace)::")[1].split("<")[0].split(">")[0].split(",")[0]
+                short = short.split("<")[0] + "<" + inner + ">"
+            rows.append({"kernel": short, "launches": entry["launches"], "avg_us": entry["avg_us"],
+                         "mb_per_launch": round(entry["hbm_bytes_per_launch"] / 1e6, 1), "gbps": entry["gbps"],
+                         "frac_of_peak": round(entry["gbps"] / HBM_PEAK_GBPS, 3)})
+    rows.sort(key=lambda r: -r["avg_us"] * r["launches"])
+    return {"peak_gbps": HBM_PEAK_GBPS, "source": os.path.relpath(path, ROOT) if path else None, "kernels": rows}
+
+
+def measured_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the newest committed counter summary, or None."""
+    _, kernels = newest_pmc_summary()
     for name, entry in kernels.items():
         if kernel in name:
             return entry["hbm_bytes_per_launch"]
@@ -91,6 +142,20 @@ def measured_traffic(kernel):
         if stem in name:
             return entry["hbm_bytes_per_launch"]
     return None
+
+
+def launch_ranks(n, argv):
+    """`python bench.py --gpus N` from a plain shell: start N fresh rank processes through torch.distributed.run as a
+    CHILD of this process, which has not touched the GPU and never will, pass their output through, and exit with
+    their status. (Replacing this process instead would be an exec; none is made.)"""
+    import socket
+    import subprocess
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    return subprocess.call(cmd)
 
 
 def main():
@@ -109,20 +174,24 @@ def main():
                          "VEGANS_HIP_GRAPH=0 so that every kernel is a dispatch of its own)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(launch_ranks(args.gpus, sys.argv[1:]))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 and world != args.gpus:
-        raise SystemExit("--gpus %d needs `python -m torch.distributed.run --nproc-per-node %d bench.py ...`" %
-                         (args.gpus, args.gpus))
+        raise SystemExit("--gpus %d, but the launcher started %d ranks" % (args.gpus, world))
     torch.cuda.set_device(local_rank % max(torch.cuda.device_count(), 1))
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         backend = os.environ.get("VEGANS_BENCH_BACKEND", "nccl")     # "gloo": rehearsal of the N > 1 flow on one GPU
+        import datetime
+        limit = datetime.timedelta(seconds=300)      # a rank that never arrives ends the run in minutes, not half an hour
         if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+            dist.init_process_group("nccl", rank=rank, world_size=world, timeout=limit,
+                                    device_id=torch.device("cuda", local_rank))
         else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
+            dist.init_process_group(backend, rank=rank, world_size=world, timeout=limit)
 
     from vegans.engine import ops, parallel, streams
 
@@ -285,7 +354,9 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": {"fp32": "f32", "bf16": "bf16", "bf16_compute": "bf16 operands, f32 tensors", "fp32_split": "f32 (3xbf16 split)"}[args.dtype], "data": "synthetic",
             "config": {"workload": "WassersteinGANGP DCGAN-64 (ngf=ndf=64, BatchNorm critic), 3x64x64, z=100, "
                                    "batch 256 per GPU, %s, steps G1:D1, RMSprop" % args.dtype,
-                       "global_batch": global_batch, "parallelism": "dp%d" % world if world > 1 else "single"},
+                       "global_batch": global_batch, "parallelism": "dp%d" % world if world > 1 else "single",
+                       "overlap": parallel.overlap_mode(model) if world > 1 else None,
+                       "backend": dist.get_backend() if world > 1 else None},
             "whole_step_conv_tflops": round(value * flops_per_image / 1e12, 2),
             "measured_through": "fit() on a numpy array: pinned upload, latent draw and the replayed HIP graph inside the "
                                 "clock (%d graph replays asserted)" % args.steps,
@@ -314,6 +385,8 @@ def main():
             out["conv_kernels"] = {"ms_per_step": round(all_ms / ROOFLINE_STEPS, 3),
                                    "aggregate_tflops": round(all_fl / (all_ms * 1e-3) / 1e12, 2)}
         out.update(extras)
+        if args.dtype == "fp32":
+            out["hbm_kernels"] = hbm_kernels()
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out))

@@ -40,7 +40,9 @@ extern "C" int vg_time_pending(void) {
 namespace {
 
 // Per image: src [R][S] -> dst [S][R] through a 32x33 LDS tile (coalesced on both sides).
-__global__ void __launch_bounds__(256) transpose_kernel(const float* __restrict__ src, float* __restrict__ dst, int R, int S) {
+// SRC = double: the batch arrives as float64 (a numpy default) and is rounded to f32 on its way through the tile.
+template <typename SRC>
+__global__ void __launch_bounds__(256) transpose_kernel(const SRC* __restrict__ src, float* __restrict__ dst, int R, int S) {
   __shared__ float tile[32][33];
   const size_t img = (size_t)blockIdx.z * R * S;
   const int s0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
@@ -48,7 +50,7 @@ __global__ void __launch_bounds__(256) transpose_kernel(const float* __restrict_
 #pragma unroll
   for (int j = 0; j < 32; j += 8) {
     const int rr = r0 + ty + j, ss = s0 + tx;
-    if (rr < R && ss < S) tile[ty + j][tx] = src[img + (size_t)rr * S + ss];
+    if (rr < R && ss < S) tile[ty + j][tx] = (float)src[img + (size_t)rr * S + ss];
   }
   __syncthreads();
 #pragma unroll
@@ -58,11 +60,12 @@ __global__ void __launch_bounds__(256) transpose_kernel(const float* __restrict_
   }
 }
 
-int launch_transpose(const char* who, const float* src, float* dst, int N, int R, int S, hipStream_t st) {
+template <typename SRC>
+int launch_transpose(const char* who, const SRC* src, float* dst, int N, int R, int S, hipStream_t st) {
   if (!(src && dst && N > 0 && R > 0 && S > 0)) return vg_fail(VG_ERR_INVALID, "%s: bad arguments", who);
   if (N > 65535) return vg_fail(VG_ERR_INVALID, "%s: batch %d exceeds the grid z limit", who, N);
   dim3 grid((S + 31) / 32, (R + 31) / 32, N);
-  hipLaunchKernelGGL(transpose_kernel, grid, dim3(256), 0, st, src, dst, R, S);
+  hipLaunchKernelGGL(transpose_kernel<SRC>, grid, dim3(256), 0, st, src, dst, R, S);
   VG_CHECK_LAUNCH(who);
   return VG_OK;
 }
@@ -194,6 +197,26 @@ __global__ void scalar_combine_kernel(const float* a, float c0, const float* b, 
 
 extern "C" int vg_nchw_to_nhwc(const float* src, float* dst, int N, int C, int HW, void* stream) {
   return launch_transpose("vg_nchw_to_nhwc", src, dst, N, C, HW, (hipStream_t)stream);
+}
+
+extern "C" int vg_nchw_to_nhwc_f64(const double* src, float* dst, int N, int C, int HW, void* stream) {
+  return launch_transpose("vg_nchw_to_nhwc_f64", src, dst, N, C, HW, (hipStream_t)stream);
+}
+
+namespace {
+__global__ void __launch_bounds__(256) narrow_kernel(const double* __restrict__ src, float* __restrict__ dst, size_t n) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) dst[i] = (float)src[i];
+}
+}  // namespace
+
+extern "C" int vg_cast_f64_to_f32(const double* src, float* dst, size_t n, void* stream) {
+  if (!(src && dst)) return vg_fail(VG_ERR_INVALID, "vg_cast_f64_to_f32: null pointer");
+  if (n == 0) return VG_OK;
+  const unsigned blocks = (unsigned)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+  hipLaunchKernelGGL(narrow_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, src, dst, n);
+  VG_CHECK_LAUNCH("vg_cast_f64_to_f32");
+  return VG_OK;
 }
 
 extern "C" int vg_nhwc_to_nchw(const float* src, float* dst, int N, int C, int HW, void* stream) {

@@ -71,6 +71,8 @@ SIGNATURES = {
     "vg_maxpool2d_bwd": (c_int, [POINTER(ConvGeom), _P, _P, _P, _P]),
     "vg_maxpool2d_pick": (c_int, [POINTER(ConvGeom), _P, _P, _P, _P]),
     "vg_nchw_to_nhwc": (c_int, [_P, _P, c_int, c_int, c_int, _P]),
+    "vg_nchw_to_nhwc_f64": (c_int, [_P, _P, c_int, c_int, c_int, _P]),
+    "vg_cast_f64_to_f32": (c_int, [_P, _P, c_size_t, _P]),
     "vg_nhwc_to_nchw": (c_int, [_P, _P, c_int, c_int, c_int, _P]),
     "vg_concat_channels": (c_int, [_P, c_int, c_int, _P, c_int, c_int, _P, c_int, c_int, _P]),
     "vg_slice_channels": (c_int, [_P, c_int, c_int, c_int, _P, c_size_t, _P]),

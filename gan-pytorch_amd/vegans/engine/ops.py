@@ -110,6 +110,24 @@ def to_nhwc(t):
     return out
 
 
+def from_float64(t):
+    """A contiguous float64 device tensor as the engine wants its inputs: float32 (round to nearest even, `.float()`),
+    images (4-d, NCHW in memory) re-laid to NHWC in the same pass."""
+    if not t.is_cuda:
+        raise _hip.HipError("input tensor is on %s: the engine only runs on the GPU" % t.device)
+    if t.dtype != torch.float64 or not t.is_contiguous():
+        raise _hip.HipError("from_float64 expects a contiguous float64 tensor")
+    if t.dim() == 4:
+        n, c, h, w = t.shape
+        out = torch.empty((n, c, h, w), dtype=torch.float32, device=t.device, memory_format=CL)
+        if t.numel():
+            call("vg_nchw_to_nhwc_f64", _ptr(t), _ptr(out), n, c, h * w, _stream())
+        return out
+    out = torch.empty(t.shape, dtype=torch.float32, device=t.device)
+    call("vg_cast_f64_to_f32", _ptr(t), _ptr(out), c_size_t(t.numel()), _stream())
+    return out
+
+
 def to_nchw(t):
     """Return `t` (N,C,H,W) with plain contiguous NCHW memory."""
     _require_gpu(t)

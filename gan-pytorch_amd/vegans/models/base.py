@@ -31,6 +31,46 @@ from ..utils import utils
 
 _COPY_STREAMS = {}      # device index -> side stream for batch uploads
 _UPLOADS_IN_FLIGHT = 2  # iterations the host may be ahead of the GPU when it uploads another batch
+_STAGING = {}           # device index -> {position of the array in a batch: _PinnedRing}
+
+
+class _PinnedRing:
+    """Page-locked staging buffers for the batches of `fit`, reused round robin. A fresh pinned allocation per batch
+    (`Tensor.pin_memory()`) costs the host several milliseconds for a 12 MB batch whenever the allocator cannot hand a
+    cached block back yet; here a batch is copied (and, for other numeric types, converted) straight into a buffer
+    that is known to be free: the event recorded behind its previous upload has completed. Buffers are keyed by shape
+    and type, so a ragged last batch gets its own."""
+
+    SLOTS = _UPLOADS_IN_FLIGHT + 2
+
+    def __init__(self):
+        self.slots = {}      # (shape, dtype) -> [[tensor, numpy view, event or None], ...]
+        self.turn = {}
+        self.last = None
+
+    def stage(self, array, dtype):
+        key = (tuple(array.shape), np.dtype(dtype).str)
+        ring = self.slots.setdefault(key, [])
+        if len(ring) < self.SLOTS:
+            t = torch.empty(tuple(array.shape), dtype=torch.float64 if np.dtype(dtype) == np.float64 else torch.float32,
+                            pin_memory=True)
+            ring.append([t, t.numpy(), None])
+            slot = ring[-1]
+        else:
+            i = self.turn.get(key, 0)
+            self.turn[key] = (i + 1) % self.SLOTS
+            slot = ring[i]
+            if slot[2] is not None:
+                slot[2].synchronize()
+        np.copyto(slot[1], array, casting="unsafe")
+        self.last = slot
+        return slot[0]
+
+    def sent(self):
+        """Call right after the asynchronous copy out of the buffer `stage` returned has been enqueued."""
+        ev = torch.cuda.Event()
+        ev.record()
+        self.last[2] = ev
 
 
 def _period(value, nr_batches):
@@ -213,18 +253,30 @@ class AbstractGenerativeModel(ABC):
     # ------------------------------------------------------------------------------------------------------
     # host -> device
     # ------------------------------------------------------------------------------------------------------
-    def _to_device(self, array):
-        """numpy batch (or tensor) -> float32 tensor on the GPU, NHWC in memory for images."""
+    def _to_device(self, array, staging=None):
+        """numpy batch (or tensor) -> float32 tensor on the GPU, NHWC in memory for images. float64 arrays (numpy's
+        default) travel as they are and are rounded to float32 on the device, in the pass that re-lays images (what
+        the reference's `.float()` does, AbstractGAN1v1.py:77). `staging`: a `_PinnedRing` whose buffers the batch is
+        staged through instead of a fresh pinned allocation per call."""
         if isinstance(array, torch.Tensor):
             t = array
             if t.dtype != torch.float32:
                 t = t.float()
             t = t.to(self.device)
+            return ops.to_nhwc(t) if t.dim() == 4 else t
+        # pinned staging + asynchronous copy: a copy from pageable memory blocks the host until the stream has
+        # drained, i.e. until the previous iteration has finished, and leaves the GPU idle during the transfer
+        array = np.asarray(array)
+        keep = array.dtype if array.dtype in (np.float32, np.float64) else np.dtype(np.float32)
+        if staging is not None:
+            host = staging.stage(array, keep)
         else:
-            # pinned staging + asynchronous copy: a copy from pageable memory blocks the host until the stream has
-            # drained, i.e. until the previous iteration has finished, and leaves the GPU idle during the transfer
-            host = torch.from_numpy(np.ascontiguousarray(array, dtype=np.float32)).pin_memory()
-            t = host.to(self.device, non_blocking=True)
+            host = torch.from_numpy(np.ascontiguousarray(array, dtype=keep)).pin_memory()
+        t = host.to(self.device, non_blocking=True)
+        if staging is not None:
+            staging.sent()
+        if t.dtype == torch.float64:
+            return ops.from_float64(t)
         return ops.to_nhwc(t) if t.dim() == 4 else t
 
     def _device_batches(self, X_train, y_train, batch_size, dp):
@@ -244,10 +296,13 @@ class AbstractGenerativeModel(ABC):
         if copy_stream is None:
             copy_stream = _COPY_STREAMS[device] = torch.cuda.Stream()
 
+        rings = _STAGING.setdefault(device, {})
+
         def upload(batch):
             parts = batch if isinstance(batch, tuple) else (batch,)
             with torch.cuda.stream(copy_stream):
-                out = tuple(self._to_device(dp.shard(part)) for part in parts)
+                out = tuple(self._to_device(dp.shard(part), rings.setdefault(i, _PinnedRing()))
+                            for i, part in enumerate(parts))
                 done = torch.cuda.Event()
                 done.record(copy_stream)
             return out, done, (dp.global_rows, getattr(dp, "local_rows", 0))

@@ -158,6 +158,11 @@ int vg_maxpool2d_pick(const vg_conv_geom* g, const float* t, const int* idx, flo
  * :672-674) and the label broadcast-concatenate of vegans/utils/utils.py:52-90. */
 int vg_nchw_to_nhwc(const float* src, float* dst, int N, int C, int HW, void* stream);
 int vg_nhwc_to_nchw(const float* src, float* dst, int N, int C, int HW, void* stream);
+/* The same boundary for float64 arrays (numpy's default dtype; the reference keeps such a batch as float64 up to
+ * `X_batch.float()`, AbstractGAN1v1.py:77, AbstractConditionalGenerativeModel.py:269): uploaded as they are and
+ * rounded to f32 (round to nearest even, what `.float()` does) on the device, images while being re-laid to NHWC. */
+int vg_nchw_to_nhwc_f64(const double* src, float* dst, int N, int C, int HW, void* stream);
+int vg_cast_f64_to_f32(const double* src, float* dst, size_t n, void* stream);
 /* out[n][p][0:C1] = a[n][p][0:C1]  (a_bcast=0)  or a[n][0:C1] tiled over the HW pixels (a_bcast=1);
  * out[n][p][C1:C1+C2] likewise from b.  NHWC; bit-exact copies. */
 int vg_concat_channels(const float* a, int C1, int a_bcast, const float* b, int C2, int b_bcast,

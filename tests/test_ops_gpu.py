@@ -477,6 +477,26 @@ def test_concat_and_layout_bit_exact(gpu):
     assert torch.equal(ops.to_nhwc(t).cpu(), t.cpu())  # logical values unchanged by a layout change
 
 
+def test_float64_batches_are_rounded_on_the_device_like_float(gpu):
+    """A float64 batch (numpy's default dtype) is uploaded as it is and rounded to float32 on the device, images in the
+    pass that re-lays them to NHWC: the result must be, bit for bit, what `.float()` gives (AbstractGAN1v1.py:77), for
+    images with ragged tile sizes, for vectors, and for values that sit exactly between two float32 neighbours (ties
+    to even)."""
+    from vegans.engine import ops
+    g = torch.Generator().manual_seed(3)
+    for shape in ((5, 3, 9, 7), (2, 11, 32, 32), (3, 1, 33, 65), (7, 20), (1, 1)):
+        x = torch.randn(shape, generator=g, dtype=torch.float64) * 3
+        flat = x.reshape(-1)
+        flat[0] = 1.0 + 2.0 ** -24            # a tie: rounds to 1.0 (even)
+        if flat.numel() > 1:
+            flat[1] = 1.0 + 3 * 2.0 ** -24    # a tie: rounds up to 1 + 2^-22 (even)
+        got = ops.from_float64(x.to(gpu))
+        assert got.dtype == torch.float32 and got.shape == x.shape
+        if x.dim() == 4:
+            assert got.is_contiguous(memory_format=torch.channels_last)
+        assert torch.equal(got.cpu(), x.float()), shape
+
+
 @pytest.mark.parametrize("fused", [False, True])
 def test_gradient_penalty_with_bn_critic_double_backward(gpu, fused):
     """Second-order path: conv -> BN -> leaky relu -> conv -> BN -> leaky relu -> conv, penalty on d out / d in;

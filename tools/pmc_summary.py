@@ -4,8 +4,9 @@
 (each in its own run: the TCC block cannot hold FETCH_SIZE and WRITE_SIZE together).
 
 usage: python tools/pmc_summary.py <dir pass1> <dir pass2> <dir pass3> <out.md> "<profiled command>"
-Also writes <out>.json: {kernel name: {"hbm_bytes_per_launch": ..., "launches": ...}}, which bench.py reads to report the
-dominant kernel's measured traffic next to its algorithmic work.
+Also writes <out>.json: {kernel name: {"hbm_bytes_per_launch", "launches", "avg_us", "read_bytes", "write_bytes", "gbps"}},
+which bench.py reads to report the dominant kernel's measured traffic next to its algorithmic work and the achieved HBM
+rate of the bandwidth-bound kernels.
 
 HBM bytes follow the gfx950 reading of the counters: FETCH_SIZE and WRITE_SIZE are in KiB, and FETCH_SIZE counts a
 128-byte request of a wide (16 B per lane) coalesced read as 64 bytes, so reads = 2 * FETCH_SIZE * 1024 (an upper
@@ -56,10 +57,12 @@ def main():
     traffic = {}
     for name, a in agg.items():
         if a["FETCH_SIZE_calls"] and a["WRITE_SIZE_calls"]:
-            traffic[name] = {
-                "hbm_bytes_per_launch": round(2.0 * a["FETCH_SIZE"] * 1024 / a["FETCH_SIZE_calls"] +
-                                              a["WRITE_SIZE"] * 1024 / a["WRITE_SIZE_calls"]),
-                "launches": int(a["calls"])}
+            rd = 2.0 * a["FETCH_SIZE"] * 1024 / a["FETCH_SIZE_calls"]
+            wr = a["WRITE_SIZE"] * 1024 / a["WRITE_SIZE_calls"]
+            us = a["ns"] / max(a["calls"], 1) / 1e3
+            traffic[name] = {"hbm_bytes_per_launch": round(rd + wr), "launches": int(a["calls"]),
+                             "avg_us": round(us, 2), "read_bytes": round(rd), "write_bytes": round(wr),
+                             "gbps": round((rd + wr) / (us * 1e-6) / 1e9, 1) if us > 0 else None}
     with open(os.path.splitext(out)[0] + ".json", "w") as f:
         json.dump({"command": cmd, "kernels": traffic}, f, indent=1, sort_keys=True)
     with open(out, "w") as f:
