@@ -121,10 +121,10 @@ def from_float64(t):
         n, c, h, w = t.shape
         out = torch.empty((n, c, h, w), dtype=torch.float32, device=t.device, memory_format=CL)
         if t.numel():
-            call("vg_nchw_to_nhwc_f64", _ptr(t), _ptr(out), n, c, h * w, _stream())
+            call("vg_nchw_to_nhwc_f64", ctypes.c_void_p(t.data_ptr()), _ptr(out), n, c, h * w, _stream())
         return out
     out = torch.empty(t.shape, dtype=torch.float32, device=t.device)
-    call("vg_cast_f64_to_f32", _ptr(t), _ptr(out), c_size_t(t.numel()), _stream())
+    call("vg_cast_f64_to_f32", ctypes.c_void_p(t.data_ptr()), _ptr(out), c_size_t(t.numel()), _stream())
     return out
 
 

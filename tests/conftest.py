@@ -33,7 +33,7 @@ def pytest_terminal_summary(terminalreporter):
         return
     used = [(n / float(size), label, key, n, size) for label, key, n, size in rows if n]
     terminalreporter.write_line("parameter tensors compared free-running: %d, with elements beyond tolerance: %d "
-                                "(allowance: %.1f%% of a tensor, at least one element)" %
+                                "(allowance: %.2f%% of a tensor, at least one element)" %
                                 (len(rows), len(used), 100 * gu.OUTLIER_FRACTION))
     for share, label, key, n, size in sorted(used, reverse=True)[:8]:
         terminalreporter.write_line("   %-12s %-28s %d of %d (%.2f%%)" % (label, key, n, size, 100 * share))
