@@ -497,12 +497,22 @@ class _NormBackwardSums:
     contraction kernel for the sums (`request` ... `take_request`), which leaves them beside the gradient (`offer`); the
     norm's backward operator takes them if, and only if, the gradient it is handed IS that tensor, unmodified
     (`claim`: same memory, same version counter, same norm). A gradient that autograd summed from several consumers
-    is another tensor (or a later version) and is reduced the ordinary way."""
+    is another tensor (or a later version) and is reduced the ordinary way.
+
+    Offers wait under the address of their gradient tensor (which the entry keeps alive, so the address names it), not
+    in one slot: between a convolution's backward and the backward of the norm in front of it autograd may run nodes of
+    other chains (the critic's fake, real and penalty passes are three chains, interleaved by node priority), and with
+    one slot whether their offers and claims displaced each other, and so whether a norm took the sums from the
+    epilogue or ran its own reduction pass, would depend on autograd's schedule instead of on the program: two runs from
+    the same seeds would differ in the last bits. Unclaimed offers are dropped at the ends of a training iteration
+    (`sweep`) and beyond MAX_PENDING."""
+
+    MAX_PENDING = 16
 
     def __init__(self):
         self.last_output = None     # (output tensor of the latest training-mode norm, its NormSource)
         self.wanted = None
-        self.ready = None           # (gradient tensor, its version, mode, geometry, per-tile sums, NormSource)
+        self.ready = {}             # address of a gradient tensor -> (tensor, its version, mode, geometry, per-tile sums, NormSource)
 
     def produced(self, y, src):
         self.last_output = (y, src)
@@ -524,12 +534,15 @@ class _NormBackwardSums:
         return src if _precision == 0 else None
 
     def offer(self, gx, mode, g, sums, src):
-        self.ready = (gx, gx._version, mode, g, sums, src)
+        self.ready.pop(gx.data_ptr(), None)
+        while len(self.ready) >= self.MAX_PENDING:
+            self.ready.pop(next(iter(self.ready)))
+        self.ready[gx.data_ptr()] = (gx, gx._version, mode, g, sums, src)
 
     def claim(self, gy, mean):
         """The per-tile sums left beside gradient `gy` for the norm whose batch mean is the tensor `mean` (allocated by
         that norm's forward call, so it names the call), or None."""
-        ready, self.ready = self.ready, None
+        ready = self.ready.pop(gy.data_ptr(), None)
         if ready is None:
             return None
         t, version, mode, g, sums, src = ready
@@ -539,8 +552,13 @@ class _NormBackwardSums:
             return None
         return mode, g, sums
 
+    def sweep(self):
+        """Drop offers nobody claimed (the boundaries of a training iteration)."""
+        self.ready.clear()
+
     def clear(self):
-        self.last_output = self.wanted = self.ready = None
+        self.last_output = self.wanted = None
+        self.ready.clear()
 
 
 norm_bwd = _NormBackwardSums()

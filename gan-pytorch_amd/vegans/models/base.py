@@ -403,6 +403,7 @@ class AbstractGenerativeModel(ABC):
 
     def _train_on_batch_body(self, X, Z):
         ops.plane_cache.begin()
+        ops.norm_bwd.sweep()
         try:
             for name in self.neural_nets:
                 for _ in range(self.steps[name]):
@@ -414,6 +415,7 @@ class AbstractGenerativeModel(ABC):
                     self._step(who=name)
         finally:
             ops.plane_cache.end()
+            ops.norm_bwd.sweep()
 
     def _draw_latent(self, n_local, dp):
         """One latent batch per data batch (AbstractGenerativeModel.py:320). The training loop never needs
@@ -759,6 +761,7 @@ class AbstractConditionalGenerativeModel(AbstractGenerativeModel):
 
     def _train_on_batch_body(self, X, y, Z):
         ops.plane_cache.begin()
+        ops.norm_bwd.sweep()
         try:
             for name in self.neural_nets:
                 for _ in range(self.steps[name]):
@@ -770,6 +773,7 @@ class AbstractConditionalGenerativeModel(AbstractGenerativeModel):
                     self._step(who=name)
         finally:
             ops.plane_cache.end()
+            ops.norm_bwd.sweep()
 
     def _log_losses(self, X_batch, Z_batch, y_batch, mode):
         self._losses = {}

@@ -340,3 +340,37 @@ def test_replayed_iteration_matches_eager_at_batch256(gpu, mode):
             assert torch.equal(s0[k], s1[k]), k
         else:
             assert s0[k] == s1[k], k
+
+
+def test_fit_runs_are_bit_identical_at_batch256(gpu):
+    """Three `fit` calls from the same seeds on fresh models (full-width DCGAN-64 WGAN-GP, batch 256, the critic's
+    passes on three streams): kernel by kernel, kernel by kernel again, and replayed from a HIP graph. Parameters and
+    BatchNorm buffers must be the same bits. At this size BatchNorm backward sums come from convolution epilogues, handed
+    from one backward node to another; which norm gets them must not depend on how autograd interleaves the three
+    chains (the interleaving differs between the first and later backward passes of a process)."""
+    import contextlib
+    import io
+
+    import bench_configs as cfg
+    from vegans.engine import graph
+    X = np.concatenate([cfg.synthetic_images(B, (3, 64, 64), seed=30 + i) for i in range(5)], axis=0)
+    case = dict(algo="wgangp", cls="WassersteinGANGP", x_dim=(3, 64, 64), z_dim=(100, 1, 1), optim_kwargs=OKW,
+                fixed_noise_size=4)
+    finals = []
+    for use_graph in (False, False, True):
+        torch.manual_seed(0)
+        np.random.seed(0)
+        m = _build_model(case, _nets() + (None,))
+        m.use_step_graph = use_graph
+        with contextlib.redirect_stdout(io.StringIO()):
+            m.fit(X, epochs=1, batch_size=B, print_every=None, save_losses_every=None, enable_tensorboard=False)
+        torch.cuda.synchronize()
+        assert graph.replays(m) == (3 if use_graph else 0)
+        finals.append({name + "." + k: v.detach().clone() for name, net in m.neural_nets.items()
+                       for k, v in net.network.state_dict().items()})
+        graph.reset(m)
+        del m
+        torch.cuda.empty_cache()
+    for other in finals[1:]:
+        for k, v in finals[0].items():
+            assert torch.equal(v, other[k]), k

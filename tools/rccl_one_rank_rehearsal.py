@@ -1,9 +1,11 @@
 """Rehearsal of the data-parallel training loop on real RCCL with the one GPU a development box has.
 
 A one-rank `nccl` process group is created and the engine is told it is rank 0 of 2, so every piece of the multi-GPU
-path runs: row sharding, the gradient buckets fed by the gradient ledger, the capture of an iteration into a chain of HIP graphs
-while RCCL's watchdog thread is alive, and RCCL all-reduces (over one rank: the identity) between the graph launches
-of every replay. Two runs from the same seeds, one replaying graphs and one eager, must end with bit-identical parameters.
+path runs: row sharding, the gradient buckets fed by the gradient ledger, the known-answer probe of stream-captured
+collectives, the capture of an iteration while RCCL's watchdog thread is alive with the bucket all-reduces inside the
+graph (the default with RCCL) or between the launches of a chain of graphs (VEGANS_DP_CAPTURE_COLLECTIVES=0), the
+agreement of the ranks about the capture, and the check of the replicas against each other after the first replay.
+Runs from the same seeds (captured, chain, eager, fenced) must end with bit-identical parameters.
 What it cannot show is the exchange between ranks itself.
     python tools/rccl_one_rank_rehearsal.py [batches] [nccl|gloo]
 """
@@ -71,8 +73,11 @@ def main():
         sharded = parallel._Sharded
         parallel._dist_on = lambda: True
         parallel._Sharded = lambda world, rank: sharded(2, 0)      # rank 0 of 2: trains on the first half of every batch
+    if dist.is_initialized():
+        os.environ["VEGANS_DP_CAPTURE_COLLECTIVES"] = "0"
     ms_graph, p_graph = run(batches, True)
-    print("graph chain + all-reduce between launches: %.2f ms per iteration (256 rows per rank)" % ms_graph, flush=True)
+    print("graph chain + all-reduce between launches (%s): %.2f ms per iteration (256 rows per rank)"
+          % (parallel.overlap_mode(), ms_graph), flush=True)
     ms_eager, p_eager = run(batches, False)
     print("eager + all-reduce as buckets complete: %.2f ms per iteration" % ms_eager, flush=True)
     _, p_graph2 = run(batches, True)
@@ -85,11 +90,14 @@ def main():
         compare("graph vs fenced graph", p_graph, p_fenced)
         if backend == "nccl":
             # the collectives captured into the iteration's graph (one graph, the all-reduces as branches on RCCL's stream)
-            os.environ["VEGANS_DP_CAPTURE_COLLECTIVES"] = "1"
+            os.environ.pop("VEGANS_DP_CAPTURE_COLLECTIVES", None)        # the default with RCCL
             try:
                 ms_cap, p_cap = run(batches, True)
-                print("one graph with the all-reduces captured: %.2f ms per iteration" % ms_cap, flush=True)
-                compare("graph vs graph with captured collectives", p_graph, p_cap)
+                print("one graph with the all-reduces captured (%s; refused: %s): %.2f ms per iteration"
+                      % (parallel.overlap_mode(), parallel._captured_refused, ms_cap), flush=True)
+                worst_cap, _ = compare("graph vs graph with captured collectives", p_graph, p_cap)
+                if parallel.overlap_mode() != "captured" or worst_cap != 0.0:
+                    raise SystemExit("captured collectives were refused or disagree with the chain")
             finally:
                 os.environ["VEGANS_DP_CAPTURE_COLLECTIVES"] = "0"
     worst, off = compare("graph vs eager", p_graph, p_eager)
