@@ -664,6 +664,14 @@ def test_wgangp_100_iterations_teacher_forced_full_width_dcgan64(gpu, capsys):
     worst tensor measured when the test was written: a 512-element BatchNorm shift at 0.9%; the 2-million-element
     weights are at 1e-4) plus the DRIFT bound on every element.
 
+    Gradients. In every tenth iteration both sub-steps are also evaluated by the oracle's code in FLOAT64 with the
+    engine's own ReLU / LeakyReLU slope decisions forced (derivative_check._MaskTap / _float64_sub_step): the exact
+    derivative of the function the engine evaluated. Every parameter tensor's gradient must be within 1e-4 of it (l2;
+    measured 1e-7 ... 4e-6), and the parameters after the step within 1e-6 of their tensor's scale of what torch's own
+    RMSprop makes of the oracle's state and that gradient. Together: each sub-step of the engine is the exact sub-step
+    of the reference up to which side of zero a handful of pre-activations fall, which no two float32 implementations
+    share.
+
     Two more engine models run for the record (printed, `per_iter` also bounded): `per_iter` is re-synchronised once per
     iteration, so its critic sub-step sees the engine's own generator update, and `free` never, whose distance from the
     oracle grows as adversarial training amplifies the differences above."""
@@ -694,6 +702,7 @@ def test_wgangp_100_iterations_teacher_forced_full_width_dcgan64(gpu, capsys):
     worst_engine, worst_oracle, direct_ok, direct_all, disagreements = {}, {}, 0, 0, []
     worst_per_iter, curve, numel = 0.0, [], {}
     grad_worst, grad_sum, grad_problems = {}, {}, []
+    exact_worst, step_worst, exact_problems = 0.0, 0.0, []
     for it in range(iters):
         X, Xd = torch.from_numpy(pool[it % len(pool)]), pool_dev[it % len(pool)]
         Z = torch.randn(B, 100, 1, 1, generator=zgen)
@@ -706,8 +715,30 @@ def test_wgangp_100_iterations_teacher_forced_full_width_dcgan64(gpu, capsys):
             alpha = A if who == "Adversariat" else None
             _sync_from_oracle(oracle, strict)
             truth = _float64_losses(oracle, who, X, Z, alpha)
-            want = oracle.sub_step(who, X, Z.clone(), None, alpha)
-            got = _engine_sub_step(strict, who, Xd, Zd)
+            if it % 10 == 9 or it == 0:
+                from derivative_check import _MaskTap, _float64_sub_step, _torch_step_on
+                with _MaskTap(strict) as tap:
+                    got = _engine_sub_step(strict, who, Xd, Zd)
+                gm = [p.grad.detach().cpu().double() for p in strict.neural_nets[who].network.parameters()]
+                _, exact = _float64_sub_step(oracle, who, X, Z, alpha, masks=tap.masks)
+                stepped = _torch_step_on(oracle, who, gm)
+                state = strict.neural_nets[who].network.state_dict()
+                for (k, _), a, b in zip(oracle.nets[who].named_parameters(), gm, exact):
+                    off = float((a - b).norm()) / max(float(b.norm()), 1e-30)
+                    exact_worst = max(exact_worst, off)
+                    if off > REL:
+                        exact_problems.append("iteration %d %s.%s: gradient %.2e (l2) from the float64 derivative under "
+                                              "the engine's own slope masks" % (it, who, k, off))
+                    e = stepped[k].detach().double()
+                    off = float((state[k].detach().cpu().double() - e).abs().max()) / max(float(e.abs().max()), 1e-2)
+                    step_worst = max(step_worst, off)
+                    if off > 1e-6:
+                        exact_problems.append("iteration %d %s.%s: %.2e of its scale from torch's RMSprop step on the "
+                                              "engine's gradient" % (it, who, k, off))
+                want = oracle.sub_step(who, X, Z.clone(), None, alpha)
+            else:
+                want = oracle.sub_step(who, X, Z.clone(), None, alpha)
+                got = _engine_sub_step(strict, who, Xd, Zd)
             for k, t in truth.items():
                 if k == "RealFakeRatio":
                     continue
@@ -765,6 +796,8 @@ def test_wgangp_100_iterations_teacher_forced_full_width_dcgan64(gpu, capsys):
         print("   gradients before the optimizer step, |engine - oracle| / |oracle| per parameter tensor (l2): " + ", ".join(
             "%s worst %.1e, mean of the per-sub-step worst %.1e" % (k, grad_worst[k], grad_sum[k] / iters)
             for k in sorted(grad_worst)))
+        print("   every tenth iteration, against the float64 derivative under the engine's own slope masks: gradients within "
+              "%.1e (l2), parameters after the step within %.1e of torch's RMSprop on that gradient" % (exact_worst, step_worst))
         print("   synchronised once per iteration instead: worst loss error %.2e of its own value" % worst_per_iter)
         print("   never synchronised: |engine - oracle| / |oracle| over all parameters (L2) after n iterations: " +
               ", ".join("%d: %.1e" % c for c in curve))
@@ -777,6 +810,7 @@ def test_wgangp_100_iterations_teacher_forced_full_width_dcgan64(gpu, capsys):
     # networks, see above and tools/teacher_forced_probe.py), the engine about twice as often as the CPU reference,
     # whose convolutions accumulate shorter chains. What is asserted here is that no tensor is beyond GRAD_L2_EVENT.
     assert not grad_problems, "\n".join(grad_problems[:40])
+    assert not exact_problems, "\n".join(exact_problems[:40])
     for key, share in average_share.items():
         assert share <= AVERAGE_SHARE_CEILING, (key, share)
     assert worst_per_iter <= PER_ITERATION_BOUND, worst_per_iter
