@@ -119,14 +119,26 @@ def hbm_kernels():
     for name, entry in kernels.items():
         if entry.get("gbps") is None:
             continue
-        short = name.split("(anonymous namespace)::")[-1].split("(")[0]
-        if any(k in short for k in HBM_KERNELS):
-            if "<" in short and "(anonymous namespace)::" in name.split("<", 1)[1]:
-                inner = name.split("<", 1)[1].split("(anonymous namespace)::")[1].split("<")[0].split(">")[0].split(",")[0]
-                short = short.split("<")[0] + "<" + inner + ">"
-            rows.append({"kernel": short, "launches": entry["launches"], "avg_us": entry["avg_us"],
-                         "mb_per_launch": round(entry["hbm_bytes_per_launch"] / 1e6, 1), "gbps": entry["gbps"],
-                         "frac_of_peak": round(entry["gbps"] / HBM_PEAK_GBPS, 3)})
+        key = next((k for k in HBM_KERNELS if k in name), None)
+        if key is None:
+            continue
+        # the kernel's name with its template arguments (balanced brackets), namespaces dropped
+        at = name.index(key) + len(key)
+        short, depth = key, 0
+        for ch in name[at:]:
+            if ch == "<":
+                depth += 1
+            elif ch == ">":
+                depth -= 1
+            elif depth == 0:
+                break
+            short += ch
+            if depth == 0:
+                break
+        short = short.replace("(anonymous namespace)::", "").replace(" >", ">")
+        rows.append({"kernel": short, "launches": entry["launches"], "avg_us": entry["avg_us"],
+                     "mb_per_launch": round(entry["hbm_bytes_per_launch"] / 1e6, 1), "gbps": entry["gbps"],
+                     "frac_of_peak": round(entry["gbps"] / HBM_PEAK_GBPS, 3)})
     rows.sort(key=lambda r: -r["avg_us"] * r["launches"])
     return {"peak_gbps": HBM_PEAK_GBPS, "source": os.path.relpath(path, ROOT) if path else None, "kernels": rows}
 
@@ -228,7 +240,22 @@ def main():
     # graphs that later iterations replay (data-parallel runs: a chain of graphs with the gradient all-reduces in
     # between); then the warm-up iterations, all inside one untimed `fit` call.
     X_timed = host_batches(args.steps)              # made ahead of the warm-up, so the GPU does not sit idle for the
-    fit_quietly(host_batches(SETUP_STEPS + args.warmup))   # time it takes to assemble it right before the timed region
+    try:                                            # time it takes to assemble it right before the timed region
+        fit_quietly(host_batches(SETUP_STEPS + args.warmup))
+    except RuntimeError as exc:
+        # First contact of captured collectives with several ranks: the engine checks the replicas against each other
+        # after the first replay (parallel.verify_replicas; every rank reaches the same verdict). Should they disagree,
+        # the benchmark starts over with the collectives between the graph launches and says so in `config.overlap`.
+        if world == 1 or "replicas disagree" not in str(exc):
+            raise
+        parallel.refuse_captured(exc)
+        graph.reset(model)
+        torch.manual_seed(0)
+        np.random.seed(0)
+        model = build_model(ngpu=world)
+        model._create_steps(None)
+        model.train()
+        fit_quietly(host_batches(SETUP_STEPS + args.warmup))
     replayed = graph.replays(model)
     fence()
     t0 = time.perf_counter()
