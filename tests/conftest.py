@@ -35,5 +35,6 @@ def pytest_terminal_summary(terminalreporter):
     terminalreporter.write_line("parameter tensors compared free-running: %d, with elements beyond tolerance: %d "
                                 "(allowance: %.2f%% of a tensor, at least one element)" %
                                 (len(rows), len(used), 100 * gu.OUTLIER_FRACTION))
+    terminalreporter.write_line("   largest single-element difference: %.2e (%s)" % tuple(gu.LARGEST_DRIFT))
     for share, label, key, n, size in sorted(used, reverse=True)[:8]:
         terminalreporter.write_line("   %-12s %-28s %d of %d (%.2f%%)" % (label, key, n, size, 100 * share))

@@ -76,6 +76,7 @@ def shadowed_keys(network):
 
 
 OUTLIER_REPORT = []     # (label, key, outliers, elements) of every tensor compare_network has looked at: printed by conftest
+LARGEST_DRIFT = [0.0, ""]   # the largest single-element difference any comparison saw, and where: printed by conftest
 
 
 def compare_network(got_state, want_state, network, rel, drift, label):
@@ -109,6 +110,8 @@ def compare_network(got_state, want_state, network, rel, drift, label):
         if outliers > allowed:
             problems.append("%s %s: %d of %d elements differ by more than %.0e * %.3e (max %.3e), allowed %d" % (
                 label, k, outliers, d.size, rel, scale, d.max(), allowed))
+        if d.max() > LARGEST_DRIFT[0]:
+            LARGEST_DRIFT[0], LARGEST_DRIFT[1] = float(d.max()), "%s %s" % (label, k)
         if d.max() > drift:
             problems.append("%s %s: an element drifted %.3e > %.1e" % (label, k, d.max(), drift))
     return problems
