@@ -193,6 +193,28 @@ with red.open(1.0) as ledger:
     except Exception as exc:
         assert "after its parameter" in str(exc), exc
 red.finish()
+
+# ---- the guards around captured collectives, on two ranks -----------------------------------------------------------
+from vegans.engine import parallel
+assert parallel.overlap_mode() == "chain"              # gloo collectives run on the host: never captured
+assert parallel._agree(True) is True
+assert parallel._agree(rank == 0) is False             # one rank failed: every rank learns it and takes the same branch
+class _Net:
+    pass
+class _Model:
+    pass
+model = _Model()
+holder = _Net()
+holder._vg_reducer = red
+model.neural_nets = {"Generator": holder}
+red.whole.fill_(1.25)
+parallel.verify_replicas(model)                        # equal buckets on both ranks: passes
+red.whole[3] = 1.25 + rank                             # rank 1 holds another value in one slot
+try:
+    parallel.verify_replicas(model)
+    raise SystemExit("unequal replicas were accepted")
+except RuntimeError as exc:
+    assert "replicas disagree" in str(exc), exc        # raised on BOTH ranks: the check itself is a collective
 dist.barrier()
 dist.destroy_process_group()
 print("rank", rank, "ok")
