@@ -23,7 +23,7 @@ import golden_util as gu
 pytestmark = pytest.mark.gpu
 
 REL = 1e-4
-DRIFT = 2e-2   # bound on every element, noise-driven ones included (see golden_util.compare_network)
+DRIFT = 1e-2   # bound on every element, noise-driven ones included (see golden_util.compare_network); largest seen: 3.7e-3
 
 
 def _build_model(case, nets, device="cuda"):
@@ -470,7 +470,7 @@ def _engine_sub_step(model, who, *batch):
 
 
 GRAD_L2 = 1e-3     # |engine gradient - oracle gradient| over |oracle gradient| (l2, per parameter tensor) of an ordinary sub-step
-GRAD_L2_EVENT = 5e-2   # ceiling for a sub-step in which one implementation took the other branch of a ReLU / LeakyReLU
+GRAD_L2_EVENT = 2.5e-2   # ceiling for a sub-step in which one implementation took the other branch of a ReLU / LeakyReLU (largest seen: 8e-3)
 
 
 def _compare_gradients(tag, who, oracle, model, skip, stats):
@@ -660,9 +660,8 @@ def test_wgangp_100_iterations_teacher_forced_full_width_dcgan64(gpu, capsys):
     An RMSprop step is lr * g / sqrt(avg g^2): an element whose gradient is rounding noise moves by a full-size step of
     either sign (from a zero state the first step is 10 * lr * sign(g) for EVERY element), and a branch flip as above
     shifts a whole layer's gradients by 1e-3 of their scale, in the reference as well. The assertion is a ceiling on the
-    share of a tensor's elements beyond tolerance averaged over all sub-steps (AVERAGE_SHARE_CEILING, about twice the
-    worst tensor measured when the test was written: a 512-element BatchNorm shift at 0.9%; the 2-million-element
-    weights are at 1e-4) plus the DRIFT bound on every element.
+    share of a tensor's elements beyond tolerance averaged over all sub-steps (AVERAGE_SHARE_CEILING, three times the
+    worst tensor measured: a 512-element BatchNorm shift at 0.32%; the 2-million-element weights are at 4e-5) plus the DRIFT bound on every element.
 
     Gradients. In every tenth iteration both sub-steps are also evaluated by the oracle's code in FLOAT64 with the
     engine's own ReLU / LeakyReLU slope decisions forced (derivative_check._MaskTap / _float64_sub_step): the exact
@@ -677,7 +676,7 @@ def test_wgangp_100_iterations_teacher_forced_full_width_dcgan64(gpu, capsys):
     oracle grows as adversarial training amplifies the differences above."""
     import bench_configs as cfg
     iters, B = 100, 64
-    AVERAGE_SHARE_CEILING = 2e-2
+    AVERAGE_SHARE_CEILING = 1e-2     # three times the worst tensor measured (3.2e-3, a 512-element BatchNorm shift)
     PER_ITERATION_BOUND = 2e-2
     floor = 1e-2
 
