@@ -42,6 +42,7 @@ class _PinnedRing:
     and type, so a ragged last batch gets its own."""
 
     SLOTS = _UPLOADS_IN_FLIGHT + 2
+    MAX_SHAPES = 4          # batch shapes kept (a full batch, a ragged last one, a test batch ...): the oldest goes first
 
     def __init__(self):
         self.slots = {}      # (shape, dtype) -> [[tensor, numpy view, event or None], ...]
@@ -50,6 +51,12 @@ class _PinnedRing:
 
     def stage(self, array, dtype):
         key = (tuple(array.shape), np.dtype(dtype).str)
+        if key not in self.slots and len(self.slots) >= self.MAX_SHAPES:
+            oldest = next(iter(self.slots))
+            for _, _, ev in self.slots.pop(oldest):      # its uploads have left the buffers before they are released
+                if ev is not None:
+                    ev.synchronize()
+            self.turn.pop(oldest, None)
         ring = self.slots.setdefault(key, [])
         if len(ring) < self.SLOTS:
             t = torch.empty(tuple(array.shape), dtype=torch.float64 if np.dtype(dtype) == np.float64 else torch.float32,
