@@ -208,6 +208,46 @@ for name, net_o in oracle.nets.items():
         assert float(ml.optimizers[name].state[pm]["step"]) == float(oracle.optimizers[name].state[po]["step"]) == iters
 print("rank %%d LSGAN/Adam data parallel vs two-device oracle: %%d problems" %% (rank, len(problems)))
 assert not problems, "\n".join(problems)
+
+# ---- a conditional class under data parallelism (an extension: the reference builds the networks of its conditional
+# 1v1 classes with ngpu=0, AbstractConditionalGAN1v1.py:42): labels are sharded by rows like images and alphas; the
+# oracle's two-device emulation with labels is the yardstick (one-hot labels tiled into planes, BatchNorm networks)
+def cond_nets():
+    return (cfg.seeded_init(cfg.cond_conv_generator(in_channels=11, ngf=8, out_channels=1), 1),
+            cfg.seeded_init(cfg.cond_conv_critic(in_channels=11, ncf=8), 2))
+
+ckw = {"Generator": {"lr": 5e-4}, "Adversariat": {"lr": 1e-4}}
+Xc = cfg.synthetic_images(B * iters, (1, 32, 32), 0.0, 1.0, seed=15)
+yc = cfg.one_hot_labels(B * iters, 10, seed=16)
+zg = torch.Generator().manual_seed(19)
+Zc = [torch.randn(B, 1, 4, 4, generator=zg) for _ in range(iters)]
+np.random.seed(31)
+Ac = [np.random.random((B, 1, 1, 1)) for _ in range(iters)]
+torch.manual_seed(3); np.random.seed(3)
+Go, Do = cond_nets()
+oracle = OracleGAN("wgangp", Go, Do, (1, 32, 32), (1, 4, 4), y_dim=(10,), optim_kwargs=copy.deepcopy(ckw), fixed_noise_size=4)
+oracle.fit(Xc, yc, epochs=1, batch_size=B, latents=[z.clone() for z in Zc], alphas=Ac, shards=world)
+torch.manual_seed(3); np.random.seed(3)
+Gm, Dm = cond_nets()
+with contextlib.redirect_stdout(io.StringIO()):
+    mc = gan.ConditionalWassersteinGANGP(Gm, Dm, x_dim=(1, 32, 32), z_dim=(1, 4, 4), y_dim=(10,), folder=None,
+                                         fixed_noise_size=4, ngpu=world, optim_kwargs=copy.deepcopy(ckw))
+zi = iter(Zc)
+mc.sample = lambda n: next(zi)[:n].to("cuda").requires_grad_(True)
+np.random.seed(31)
+with contextlib.redirect_stdout(io.StringIO()):
+    mc.fit(Xc, yc, epochs=1, batch_size=B, print_every=None, save_losses_every=None, enable_tensorboard=False)
+problems = []
+for name, net_o in oracle.nets.items():
+    want = {k: v.detach().numpy() for k, v in net_o.state_dict().items()}
+    network = mc.neural_nets[name].network
+    got = network.state_dict()
+    if rank != 0:
+        want = {k: v for k, v in want.items() if "running_" not in k}
+        got = {k: v for k, v in got.items() if "running_" not in k}
+    problems += gu.compare_network(got, want, network, 1e-4, 1e-2, name)
+print("rank %%d conditional WGAN-GP data parallel vs two-device oracle: %%d problems" %% (rank, len(problems)))
+assert not problems, "\n".join(problems)
 dist.barrier(); dist.destroy_process_group()
 print("rank", rank, "ok")
 '''
