@@ -269,7 +269,7 @@ def probe_captured_collectives():
         return
     _probed = True
     world, rank = dist.get_world_size(), dist.get_rank()
-    ok, why = True, ""
+    ok, why, g, buf = True, "", None, None
     try:
         buf = torch.zeros(4096, device="cuda")
         side = torch.cuda.Stream()
@@ -285,18 +285,25 @@ def probe_captured_collectives():
             finally:
                 g.capture_end()
         torch.cuda.current_stream().wait_stream(side)
+    except Exception as exc:   # noqa: BLE001 - whatever the communication library or the capture raises
+        ok, why = False, "%s: %s" % (type(exc).__name__, exc)
+    # Nothing has been exchanged yet (a capture executes nothing). Only if EVERY rank holds a graph are the graphs
+    # replayed: a rank that replayed alone would wait in its all-reduce for ranks that never enter theirs.
+    if not _agree(ok):
+        refuse_captured(why or "another rank could not capture an all-reduce")
+        return
+    try:
         for k in range(3):
             buf.fill_(float(rank + 1 + k))
             g.replay()
             torch.cuda.synchronize()
             want = world * (world + 1) / 2.0 + k * world
-            if not bool((buf == want).all()):
+            if ok and not bool((buf == want).all()):
                 ok, why = False, "a replayed all-reduce returned %r instead of %r" % (float(buf[0]), want)
-                break
-    except Exception as exc:   # noqa: BLE001 - whatever the communication library or the capture raises
+    except Exception as exc:   # noqa: BLE001
         ok, why = False, "%s: %s" % (type(exc).__name__, exc)
     if not _agree(ok):
-        refuse_captured(why or "another rank's probe of captured collectives failed")
+        refuse_captured(why or "another rank's replayed all-reduce returned wrong values")
 
 
 def _cut_for_collectives():
