@@ -379,6 +379,194 @@ __global__ void __launch_bounds__(256) dgrad_scatter_kernel(const TG* __restrict
   }
 }
 
+
+// ---- dgrad, Ci <= 4, scatter form, persistent blocks (4 x 4 kernel, stride 2, 32 or 64 gradient channels) ----------------
+// The arithmetic of dgrad_scatter_kernel for the shape image heads have, arranged so that a launch is not a sequence of
+// phases all blocks go through together (fetch, products, gather: each of them idle for the other two thirds of the time,
+// which is what the phase-by-phase timing of that kernel shows): a block walks several tiles, the w fragments of all
+// channels stay in registers for the block's lifetime, the next tile's gradient values are in flight while the current
+// tile's products run, and the blocks of a compute unit drift apart so that one block's products overlap another's
+// gather. A fragments are read 16 bytes at a time: the k order inside a 32-channel chunk is free as long as both operands
+// agree, so lane (r, kq) takes channels 16 jj + 4 kq + e (e = 0..3) for its eight products of a chunk. The gather phase
+// has compile-time tap loops and writes 16 bytes per lane, straight from the sums (an output row segment of the tile is
+// contiguous in memory, so lane l's four floats follow lane l - 1's).
+template <int CI, int NCH, class TG>
+__global__ void __launch_bounds__(256) dgrad_scatter42_kernel(const TG* __restrict__ gy, const float* __restrict__ w,
+                                                              const float* __restrict__ bias, float* __restrict__ gx, int H,
+                                                              int W, int Ho, int Wo, int ph, int pw, int rw_log2,
+                                                              int tiles_h, int step_h, int org_h, int total_tiles) {
+  constexpr int KK = 4, S = 2, NT = 2, Co = 32 * NCH;
+  constexpr int NP = KK * KK * CI, LDP = NP | 1, NTN = (NP + 15) / 16, LDS_ = 36;
+  static_assert(LDS_ <= LDP, "the staging tile shares the partials' memory");
+  __shared__ float part[256 * LDP];
+  float* stage = part;
+  typedef float f32x4_acc __attribute__((ext_vector_type(4)));
+  const int RW = 1 << rw_log2, RH = 256 >> rw_log2;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r = lane & 15, kq = lane >> 4;
+  if ((int)blockIdx.x >= total_tiles) return;
+
+  float bfr[NCH][2][4][NTN];
+#pragma unroll
+  for (int ch = 0; ch < NCH; ++ch)
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int nt = 0; nt < NTN; ++nt) {
+          const int co = 32 * ch + 16 * jj + 4 * kq + e, col = 16 * nt + r;
+          bfr[ch][jj][e][nt] = col < NP ? w[co * NP + col] : 0.f;
+        }
+  float b[CI];
+#pragma unroll
+  for (int c = 0; c < CI; ++c) b[c] = bias ? bias[c] : 0.f;
+
+  // the 8 (pixel, 4-channel group) slots this thread fetches per 32-channel chunk: element offsets into gy, -1 = none
+  int src[8];
+  unsigned valid = 0;
+  auto offsets = [&](int tile) __attribute__((always_inline)) {
+    const int n = tile / tiles_h, h0 = (tile - n * tiles_h) * step_h + org_h;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int pp = (threadIdx.x >> 3) + 32 * j;
+      const int qh = h0 + (pp >> rw_log2), qw = pp & (RW - 1);
+      const bool ok = (unsigned)qh < (unsigned)Ho && qw < Wo;
+      src[j] = ok ? ((n * Ho + qh) * Wo + qw) * Co + 4 * (int)(threadIdx.x & 7) : 0;
+      valid = ok ? valid | (1u << j) : valid & ~(1u << j);
+    }
+  };
+  // Loads without conditions around them (a slot outside the image reads element 0 and is zeroed when it is written to
+  // LDS): the compiler can then count the loads in flight, and the products of a chunk do not wait for the next chunk's
+  // values.
+  f32x4 pre[8];
+  unsigned pre_valid = 0;
+  auto fetch = [&](int cc0) __attribute__((always_inline)) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) pre[j] = vg_ld4(gy + src[j] + cc0);
+    pre_valid = valid;
+  };
+  offsets(blockIdx.x);
+  fetch(0);
+  // the weight fragments and the bias have arrived before the tile loop starts: nothing inside it waits for them
+#pragma unroll
+  for (int ch = 0; ch < NCH; ++ch)
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int nt = 0; nt < NTN; ++nt) asm volatile("" : "+v"(bfr[ch][jj][e][nt]));
+#pragma unroll
+  for (int c = 0; c < CI; ++c) asm volatile("" : "+v"(b[c]));
+  const int rowf = W * CI;                                   // floats of one output row
+  // Gather phase: a thread owns four consecutive floats of an output row, the same column position in every pass (rpp rows
+  // per pass), so everything that depends on the column is worked out once: per float the offset of its (gy column
+  // qw, tap kw = (wi + pw) % 2) partial within a gy row of `part`, whether columns qw and qw - 1 exist, and its bias.
+  const int t4 = rowf >> 2, rpp = 256 / t4;
+  const int grow = threadIdx.x / t4, gcol = threadIdx.x - grow * t4;
+  const bool gactive = grow < rpp;
+  int goff[4];
+  unsigned gok = 0;
+  float gbias[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int idx = 4 * gcol + e;
+    const int wi = idx / CI, c = idx - wi * CI;
+    const int qw = (wi + pw) >> 1, kw0 = (wi + pw) & 1;
+    goff[e] = qw * LDP + kw0 * CI + c;
+    gok |= (qw < Wo ? 1u : 0u) << (2 * e);                 // bb = 0: column qw
+    gok |= (qw >= 1 && qw - 1 < Wo ? 1u : 0u) << (2 * e + 1);   // bb = 1: column qw - 1, tap kw0 + 2
+    float bv = b[0];
+#pragma unroll
+    for (int cc = 1; cc < CI; ++cc) bv = c == cc ? b[cc] : bv;
+    gbias[e] = bv;
+  }
+  for (int tile = blockIdx.x; tile < total_tiles; tile += gridDim.x) {
+    const int n = tile / tiles_h, h0 = (tile - n * tiles_h) * step_h + org_h;
+    f32x4_acc macc[4][NTN];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NTN; ++nt) macc[mt][nt] = f32x4_acc{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch) {
+      __syncthreads();            // the readers of the memory `stage` shares (this tile's products, the last tile's gather)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+        *reinterpret_cast<f32x4*>(&stage[((threadIdx.x >> 3) + 32 * j) * LDS_ + 4 * (threadIdx.x & 7)]) =
+            (pre_valid >> j) & 1u ? pre[j] : zero;
+      }
+      if (ch + 1 < NCH) {
+        fetch(32 * (ch + 1));
+      } else if (tile + (int)gridDim.x < total_tiles) {
+        offsets(tile + gridDim.x);
+        fetch(0);
+      }
+      __syncthreads();
+      f32x4 a4[4][2];
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj)
+          a4[mt][jj] = *reinterpret_cast<const f32x4*>(&stage[(64 * wave + 16 * mt + r) * LDS_ + 16 * jj + 4 * kq]);
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+          for (int nt = 0; nt < NTN; ++nt)
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+              macc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[mt][jj][e], bfr[ch][jj][e][nt], macc[mt][nt], 0, 0, 0);
+      // what follows (the next chunk's values arriving, their way into LDS) waits for memory: not among the products
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    __syncthreads();
+    // accumulator element e of a lane is row 4 kq + e, column r of its 16 x 16 tile
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NTN; ++nt) {
+        const int col = 16 * nt + r;
+        if (col < NP) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) part[(64 * wave + 16 * mt + 4 * kq + e) * LDP + col] = macc[mt][nt][e];
+        }
+      }
+    __syncthreads();
+    // output rows owned by this tile: those whose lowest contributing gy row lies in [h0, h0 + step_h) (all rows when one
+    // tile spans the image); a row segment is W * CI consecutive floats, handled four at a time
+    const int hi_lo = tiles_h == 1 ? 0 : S * (h0 - 1) - ph + KK, OH = tiles_h == 1 ? H : S * step_h;
+    float* const obase = gx + ((long long)n * H + hi_lo) * rowf;
+    for (int oy = grow; oy < OH; oy += rpp) {
+      const int hi = hi_lo + oy;
+      if ((unsigned)hi >= (unsigned)H || !gactive) continue;
+      // gy rows that reach output row hi: qq = floor((hi + ph) / 2) - a with tap kh = (hi + ph) % 2 + 2 a
+      const int qh = (hi + ph) >> 1, kh0 = (hi + ph) & 1;
+      f32x4 out;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) out[e] = gbias[e];
+#pragma unroll
+      for (int a = 0; a < NT; ++a) {
+        const int qq = qh - a, ry = qq - h0;
+        const bool rowok = qq >= 0 && qq < Ho && (unsigned)ry < (unsigned)RH;
+        const int rowoff = (ry << rw_log2) * LDP + (kh0 + 2 * a) * KK * CI;
+#pragma unroll
+        for (int bb = 0; bb < NT; ++bb)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const bool ok = rowok && ((gok >> (2 * e + bb)) & 1u);
+            const float t = part[ok ? rowoff + goff[e] + bb * (2 * CI - LDP) : 0];
+            out[e] += ok ? t : 0.f;
+          }
+      }
+      *reinterpret_cast<f32x4*>(obase + oy * rowf + 4 * gcol) = out;
+    }
+  }
+}
+
 }  // namespace
 
 // Returns 1 if the thin forward kernel took the call, 0 if the shape does not qualify, < 0 on error.
@@ -839,6 +1027,33 @@ static int try_dgrad_scatter(const vg_conv_geom* g, const void* gy, const float*
   if (best_rw == 0) return 0;
   const long long grid = best_blocks * g->N;
   if (grid > 0x7fffffffLL) return 0;
+  // the image-head shape (4 x 4, stride 2, 32 or 64 gradient channels, one tile across the width): persistent blocks
+  if (taps == 16 && g->kh == 4 && g->sh == 2 && g->sw == 2 && bt_w == 1 && (g->Ci == 3 || g->Ci == 4) &&
+      (g->Co == 32 || g->Co == 64) && (g->W * g->Ci) % 4 == 0 && vg_aligned16(gx) &&
+      (long long)g->N * g->Ho * g->Wo * g->Co < 0x7fffffffLL && (long long)g->H * g->W * g->Ci * 2 < (1 << 22)) {
+    int lg = 0;
+    while ((1 << lg) < best_rw) ++lg;
+    // two blocks per compute unit (what the kernel's registers allow), each walking every 512th tile: with the 1280
+    // tiles of a batch of 256 images of 64 x 64 a compute unit gets 3 + 2 tiles. Measured on that shape: 27.5 us at 512
+    // blocks, 31.4 at 256, 29.3 at 768, 33.2 with one tile per block (44 for dgrad_scatter_kernel).
+    const long long cap = 512;
+    const unsigned blocks = (unsigned)(grid < cap ? grid : cap);
+#define THIN_SCATTER42(CI_, NCH_)                                                                                        \
+    if (g->Ci == CI_ && g->Co == 32 * NCH_) {                                                                            \
+      if (gy_h)                                                                                                          \
+        vg_launch_timed(dgrad_scatter42_kernel<CI_, NCH_, __bf16>, dim3(blocks), dim3(256), 0, st, (const __bf16*)gy, w,  \
+                        bias, gx, g->H, g->W, g->Ho, g->Wo, g->ph, g->pw, lg, bt_h, bs_h, bo_h, (int)grid);                \
+      else                                                                                                               \
+        vg_launch_timed(dgrad_scatter42_kernel<CI_, NCH_, float>, dim3(blocks), dim3(256), 0, st, (const float*)gy, w,    \
+                        bias, gx, g->H, g->W, g->Ho, g->Wo, g->ph, g->pw, lg, bt_h, bs_h, bo_h, (int)grid);                \
+    }
+    THIN_SCATTER42(3, 1) THIN_SCATTER42(3, 2) THIN_SCATTER42(4, 1) THIN_SCATTER42(4, 2)
+#undef THIN_SCATTER42
+    hipError_t e42 = hipGetLastError();
+    if (e42 != hipSuccess)
+      return vg_fail(VG_ERR_LAUNCH, "vg_conv2d_dgrad(scatter): launch failed: %s", hipGetErrorString(e42));
+    return 1;
+  }
 #define THIN_SCATTER(CI_, TAPS_)                                                                                        \
   if (g->Ci == CI_ && taps == TAPS_) {                                                                                  \
     if (gy_h)                                                                                                           \

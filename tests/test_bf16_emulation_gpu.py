@@ -24,6 +24,7 @@ import torch
 from torch import nn
 
 import golden_util as gu  # noqa: F401
+from derivative_check import _torch_step_on
 from test_batch256_gpu import OKW, _Forced, _MaskTap, _nets
 from test_models_gpu import _oracle_and_model, _sync_from_oracle
 
@@ -31,6 +32,7 @@ pytestmark = pytest.mark.gpu
 
 LOSS_TOL = {"bf16": 1e-2, "bf16_compute": 1e-2}     # of the loss's own value (floor 1e-1; the critic total at its largest term)
 GRAD_TOL = {"bf16": 2e-2, "bf16_compute": 2e-2}     # l2, per parameter tensor
+STEP_TOL = 1e-6     # parameters after the optimizer step, of a tensor's scale, from torch's step on the engine's gradient
 
 
 def _emulated_sub_step(oracle, who, X, Z, alpha, mode, masks):
@@ -107,7 +109,7 @@ def test_bf16_modes_teacher_forced_vs_their_cpu_restatement(gpu, capsys, mode):
         model._create_steps(None)
         model.train()
         zgen = torch.Generator().manual_seed(10)
-        problems, worst_loss, worst_grad = [], {}, {}
+        problems, worst_loss, worst_grad, worst_step = [], {}, {}, 0.0
         for it in range(iters):
             Xn = cfg.synthetic_images(B, (3, 64, 64), seed=40 + it)
             X, Xd = torch.from_numpy(Xn), model._to_device(Xn)
@@ -125,6 +127,7 @@ def test_bf16_modes_teacher_forced_vs_their_cpu_restatement(gpu, capsys, mode):
                 got = {k: float(v.detach()) for k, v in model._losses.items()}
                 gm = [p.grad.detach().cpu().double() for p in model.neural_nets[who].network.parameters()]
                 want, ge, names = _emulated_sub_step(oracle, who, X, Z, alpha, mode, tap.masks)
+                shadow = _torch_step_on(oracle, who, gm)
                 plain = oracle.sub_step(who, X, Z.clone(), None, alpha)
                 g32 = [p.grad.detach().double() for p in oracle.nets[who].parameters()]
                 model._step(who=who)
@@ -148,6 +151,16 @@ def test_bf16_modes_teacher_forced_vs_their_cpu_restatement(gpu, capsys, mode):
                     worst_grad[key] = tuple(max(x, y) for x, y in zip(worst_grad.get(key, (0.0, 0.0)), (e, f)))
                     if e > GRAD_TOL[mode]:
                         problems.append("%s gradient of %s: %.2e (l2) from the restatement's" % (tag, key, e))
+                # the parameters are f32 masters in every mode: after the step they are what torch's own RMSprop makes
+                # of the oracle's state and the ENGINE's gradient
+                state = model.neural_nets[who].network.state_dict()
+                for k, e in shadow.items():
+                    a, e = state[k].detach().cpu().double(), e.detach().double()
+                    off = float((a - e).abs().max()) / max(float(e.abs().max()), 1e-2)
+                    worst_step = max(worst_step, off)
+                    if off > STEP_TOL:
+                        problems.append("%s %s.%s: %.2e of its scale from torch's RMSprop step on the engine's gradient"
+                                        % (tag, who, k, off))
     finally:
         ops.set_matmul_precision(previous)
     with capsys.disabled():
@@ -158,4 +171,6 @@ def test_bf16_modes_teacher_forced_vs_their_cpu_restatement(gpu, capsys, mode):
         print("   gradients (l2), worst over the sub-steps: from the restatement | from the fp32 oracle")
         for k in sorted(worst_grad):
             print("      %-28s %.1e | %.1e" % ((k,) + worst_grad[k]))
+        print("   parameters after the step: at most %.1e of a tensor's scale from torch's RMSprop on the engine's gradient"
+              % worst_step)
     assert not problems, "\n".join(problems[:40])

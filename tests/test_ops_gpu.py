@@ -42,6 +42,11 @@ CONV_CASES = [
     (5, 1, 21, 70, 64, 4, 2, 1),     # stem kernel, Ci=1, several column tiles with a ragged last one
     (6, 3, 11, 9, 128, 3, 1, 1),     # stem weight-gradient kernel: odd K = 27, two channel tiles, ragged pixel tiles
     (3, 1, 30, 30, 64, 5, 2, 2),     # stem weight-gradient kernel: Ci=1, 5x5 stride 2, more slabs than tiles
+    # persistent scatter-form input gradient (4x4 stride 2, 3 or 4 image channels, 32 or 64 feature channels)
+    (3, 3, 20, 28, 64, 4, 2, 1),     # one tile spans the gradient image's height
+    (2, 4, 37, 21, 32, 4, 2, 1),     # Ci=4, 32 channels, two row tiles, odd sizes
+    (5, 3, 70, 40, 32, 4, 2, 0),     # no padding, five row tiles per image, more tiles than one pass of blocks may hold
+    (2, 3, 66, 64, 64, 4, 2, 2),     # padding 2: 33 gradient columns in 64-wide tiles of 4 rows
     # the benchmark's own launches: DCGAN-64 critic layers at batch 256 (the split-K plan, grid sizes and slab set of
     # that batch; the other cases run at a few images)
     (256, 3, 64, 64, 64, 4, 2, 1),   # image stem: 262144 output pixels
