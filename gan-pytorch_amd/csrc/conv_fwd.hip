@@ -296,7 +296,8 @@ extern "C" int vg_conv2d_variant(int mode, const vg_conv_geom* g, char* buf, siz
   const int bn = igemm_pick_bn(ncols);
   const int bm = mode == 2 ? (rows <= 64 && bn != 32 ? 64 : 128) : igemm_pick_bm(rows, (ncols + bn - 1) / bn, zdim, bn);
   // trailing arguments: precision 0 = the f32 instance (what the un-suffixed entry points run), then waves per block
-  const int nw = igemm_waves(bm, bn, va, vb, PREC_F32);
+  const int nw = igemm_waves(bm, bn, va, vb, PREC_F32,
+                             igemm_small24(g->N, g->H, g->W, g->Ci, g->Co, g->kh, g->kw, g->Ho, g->Wo));
   // (last argument: the variant without column statistics; a convolution asked to leave BatchNorm statistics runs the
   // instance that ends in "true")
   snprintf(buf, len, "igemm_kernel<%d, %d, %d, %d, %s, %d, %d, 0, %d, 0>", kmode, bm, bn, igemm_waves_m(bm, bn, nw),

@@ -604,29 +604,6 @@ __global__ void __launch_bounds__(256) stem_fwd_kernel(const float* __restrict__
   const int co0 = blockIdx.y * 64;
   const bool two = co0 + 32 < Co;     // the second 32-channel tile exists
 
-  // the block's 64 weight rows come in coalesced through LDS; lane (col = r, half = h) keeps w[co0 + 32 t + r][2 j + h]
-  // in registers for all the tiles the block walks
-  for (int i = threadIdx.x; i < 64 * K; i += 256) {
-    const int row = i / K, k = i - row * K;
-    wsm[row * LDW + k] = co0 + row < Co ? w[(size_t)(co0 + row) * K + k] : 0.f;
-  }
-  __syncthreads();
-  float bw[2][KP];
-#pragma unroll
-  for (int t = 0; t < 2; ++t)
-#pragma unroll
-    for (int j = 0; j < KP; ++j) {
-      const int k = 2 * j + h;
-      bw[t][j] = k < K ? wsm[(32 * t + r) * LDW + k] : 0.f;
-    }
-  float bv[2];
-#pragma unroll
-  for (int t = 0; t < 2; ++t) bv[t] = (bias && co0 + 32 * t + r < Co) ? bias[co0 + 32 * t + r] : 0.f;
-  // Pin the arrival of the bias values here. Their first use is inside the conditionally executed store blocks below;
-  // left there, every one of those blocks gets its own wait for all outstanding memory operations, which also waits
-  // for the store before it and serialises the stores.
-  asm volatile("" ::"v"(bv[0]), "v"(bv[1]));
-
   // patch element i of a thread: row pr, pixel px, channel pc (the same for every tile)
   constexpr int PPT = (PH * ROWF + 255) / 256;
   int p_row[PPT], p_px[PPT], p_c[PPT];
@@ -656,12 +633,48 @@ __global__ void __launch_bounds__(256) stem_fwd_kernel(const float* __restrict__
       pre[u] = *ptr;
     }
   };
+  // the first tile's patch is on its way while the weights come in
+  if ((int)blockIdx.x < tiles_total) fetch_patch(blockIdx.x);
+  // the block's 64 weight rows come in coalesced through LDS; lane (col = r, half = h) keeps w[co0 + 32 t + r][2 j + h]
+  // in registers for all the tiles the block walks (all loads first, without conditions around them, then the LDS
+  // writes: written as one loop, every element waited for its own trip to memory)
+  constexpr int WPT = (64 * K + 255) / 256;
+  float wv[WPT];
+#pragma unroll
+  for (int u = 0; u < WPT; ++u) {
+    const int i = threadIdx.x + 256 * u;
+    const int row = i / K;
+    const bool ok = i < 64 * K && co0 + row < Co;
+    wv[u] = w[ok ? (size_t)co0 * K + i : 0];
+  }
+#pragma unroll
+  for (int u = 0; u < WPT; ++u) {
+    const int i = threadIdx.x + 256 * u;
+    const int row = i / K, k = i - row * K;
+    if (i < 64 * K) wsm[row * LDW + k] = co0 + row < Co ? wv[u] : 0.f;
+  }
+  __syncthreads();
+  float bw[2][KP];
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int j = 0; j < KP; ++j) {
+      const int k = 2 * j + h;
+      bw[t][j] = k < K ? wsm[(32 * t + r) * LDW + k] : 0.f;
+    }
+  float bv[2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t) bv[t] = (bias && co0 + 32 * t + r < Co) ? bias[co0 + 32 * t + r] : 0.f;
+  // Pin the arrival of the bias values here. Their first use is inside the conditionally executed store blocks below;
+  // left there, every one of those blocks gets its own wait for all outstanding memory operations, which also waits
+  // for the store before it and serialises the stores.
+  asm volatile("" ::"v"(bv[0]), "v"(bv[1]));
+
   // Two patch buffers. Per tile: the next tile's patch is requested, the matrix cores run on the current buffer, the
   // arrived values go to the other buffer and only then are this tile's results stored. The stores thus drain under
   // the next tile's products: the wait for the patch loads (the memory counter completes in order) falls behind them,
   // where the previous tile's stores have long finished, instead of directly after a tile's own stores.
   if ((int)blockIdx.x < tiles_total) {
-    fetch_patch(blockIdx.x);
 #pragma unroll
     for (int u = 0; u < PPT; ++u) {
       const int i = threadIdx.x + 256 * u;

@@ -98,6 +98,24 @@ __global__ void __launch_bounds__(NW * 64, NW == 8 ? 4 : 1) igemm_kernel(const I
   constexpr bool A_MC = (MODE == MODE_WGRAD);
   constexpr bool B_IS_MC = B_MC || (MODE != MODE_FWD);
   static_assert(TM >= 1 && TN >= 1, "tile too small for the wave arrangement");
+  // Products of the address arithmetic inside the k loop. A full 32-bit integer multiply runs at a quarter of the vector
+  // rate (16 cycles per wave), and vector instructions do not overlap the matrix instructions of the same SIMD, not
+  // even another wave's (measured: tools/probes/mfma_valu_overlap.hip), so the 8 to 14 products of a k-step cost as
+  // much as two or three MFMAs. The eight-wave variants multiply 24-bit operands (one full-rate instruction, fusable
+  // with the addition behind it); the host hands them only geometries whose factors are below 2^24 (igemm_small24)
+  // and everything else to the four-wave variants.
+  // (Written as an instruction: through __mul24 the compiler sees that only the low bits of an inner product are used
+  // by the outer one, drops the 24-bit extensions and is back at v_mul_lo_u32. The second factor is block-uniform.)
+  constexpr bool M24 = NW == 8 && !BF;
+  auto mul = [](int a, int uniform) -> int {
+    if constexpr (M24) {
+      int r;
+      asm("v_mul_i32_i24 %0, %2, %1" : "=v"(r) : "v"(a), "s"(uniform));
+      return r;
+    } else {
+      return a * uniform;
+    }
+  };
 
   // two staging buffers: tile t+1 is written while tile t is being read, one barrier per k-step
   constexpr int A_FLOATS = BF ? (A_MC ? (BK / 2) * BM : BM * LDB / 2) : (A_MC ? BK * BM : BM * LDK);
@@ -327,7 +345,7 @@ __global__ void __launch_bounds__(NW * 64, NW == 8 ? 4 : 1) igemm_kernel(const I
       } else {
         // wgrad A = gy[pixel][co], tile [k][m]
         const int pix = kpos + krowA(i);
-        const unsigned off = ((unsigned)pix * (unsigned)p.Co + (unsigned)(m0 + 4 * (tid % TPRA))) * 4u;
+        const unsigned off = ((unsigned)mul(pix, p.Co) + (unsigned)(m0 + 4 * (tid % TPRA))) * 4u;
         oa[i] = (pix < kend ? off : OOB) | m4ok_mask;
       }
     }
@@ -340,21 +358,21 @@ __global__ void __launch_bounds__(NW * 64, NW == 8 ? 4 : 1) igemm_kernel(const I
       } else if constexpr (MODE == MODE_FWD) {
         // plain GEMM operand B[k][n] (row stride Ncols)
         const int k = kpos + krowB(i);
-        ob[i] = (k < kend ? ((unsigned)k * (unsigned)p.Ncols + (unsigned)bn4) * 4u : OOB) | bn4_mask;
+        ob[i] = (k < kend ? ((unsigned)mul(k, p.Ncols) + (unsigned)bn4) * 4u : OOB) | bn4_mask;
       } else if constexpr (MODE == MODE_DGRAD) {
         // weights w[co][kh][kw][ci] read as B[k=(tap,co)][n=ci]
         const int k = kpos + krowB(i);
-        const int bta = vg_div_small(bk_t[i], inv_ntw), btb = bk_t[i] - bta * ntw;
-        const int kh = cls_h + p.sh * bta, kw = cls_w + p.sw * btb;
-        const unsigned off = ((unsigned)((bk_co[i] * p.KH + kh) * p.KW + kw) * (unsigned)p.Ci + (unsigned)bn4) * 4u;
+        const int bta = vg_div_small(bk_t[i], inv_ntw), btb = bk_t[i] - mul(bta, ntw);
+        const int kh = cls_h + mul(bta, p.sh), kw = cls_w + mul(btb, p.sw);
+        const unsigned off = ((unsigned)mul(mul(mul(bk_co[i], p.KH) + kh, p.KW) + kw, p.Ci) + (unsigned)bn4) * 4u;
         ob[i] = (k < kend ? off : OOB) | bn4_mask;
       } else {
         // wgrad B = x window, tile [k=pixel][n=(kh,kw,ci)]
         const int pix = kpos + krowB(i);
-        const int bpn = vg_div_small(bp_row[i], inv_ho), bpho = bp_row[i] - bpn * p.Ho;
-        const int hi = bpho * p.sh - p.ph + b_ta[0], wi = bp_wo[i] * p.sw - p.pw + b_tb[0];
+        const int bpn = vg_div_small(bp_row[i], inv_ho), bpho = bp_row[i] - mul(bpn, p.Ho);
+        const int hi = mul(bpho, p.sh) - p.ph + b_ta[0], wi = mul(bp_wo[i], p.sw) - p.pw + b_tb[0];
         const bool ok = (pix < kend) & ((unsigned)hi < (unsigned)p.H) & ((unsigned)wi < (unsigned)p.W);
-        ob[i] = ok ? ((unsigned)((bpn * p.H + hi) * p.W + wi) * (unsigned)p.Ci + (unsigned)b_ci[0]) * 4u : OOB;
+        ob[i] = ok ? ((unsigned)mul(mul(mul(bpn, p.H) + hi, p.W) + wi, p.Ci) + (unsigned)b_ci[0]) * 4u : OOB;
       }
     }
   };
@@ -363,9 +381,9 @@ __global__ void __launch_bounds__(NW * 64, NW == 8 ? 4 : 1) igemm_kernel(const I
       if (q == 0) {
         pt_kvalid = kpos + 4 * (tid & 7) < kend;
         pt_ta = vg_div_small(ak_t, inv_ntw);
-        pt_tb = ak_t - pt_ta * ntw;
-        if constexpr (MODE == MODE_FWD) pt_tap = ((unsigned)(pt_ta * p.W + pt_tb) * (unsigned)p.Ci + (unsigned)ak_c) * 4u;
-        else pt_tap = ((unsigned)ak_c - (unsigned)(pt_ta * p.Wo + pt_tb) * (unsigned)p.Co) * 4u;
+        pt_tb = ak_t - mul(pt_ta, ntw);
+        if constexpr (MODE == MODE_FWD) pt_tap = ((unsigned)mul(mul(pt_ta, p.W) + pt_tb, p.Ci) + (unsigned)ak_c) * 4u;
+        else pt_tap = ((unsigned)ak_c - (unsigned)mul(mul(pt_ta, p.Wo) + pt_tb, p.Co)) * 4u;
       }
     }
 #pragma unroll
@@ -958,6 +976,18 @@ __global__ void __launch_bounds__(NW * 64, NW == 8 ? 4 : 1) igemm_kernel(const I
     }
     has_bias = false;
   }
+  // dgrad: the lane's row offsets come out of LDS in one go, four at a time (rows 4 h + 8 q + 0..3 are neighbours), ahead
+  // of the store loop: read one by one inside it, every store waited for an LDS round trip of its own
+  unsigned offs[MODE == MODE_DGRAD ? TM : 1][16];
+  if constexpr (MODE == MODE_DGRAD) {
+#pragma unroll
+    for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const uint4 t = *reinterpret_cast<const uint4*>(&row_off[(wm * TM + mi) * 32 + 4 * h + 8 * q]);
+        offs[mi][4 * q] = t.x; offs[mi][4 * q + 1] = t.y; offs[mi][4 * q + 2] = t.z; offs[mi][4 * q + 3] = t.w;
+      }
+  }
 #pragma unroll
   for (int mi = 0; mi < TM; ++mi) {
     const int row_t = m0 + (wm * TM + mi) * 32 + 4 * h;      // first of the lane's 16 rows of this tile
@@ -969,7 +999,7 @@ __global__ void __launch_bounds__(NW * 64, NW == 8 ? 4 : 1) igemm_kernel(const I
       const int row = row_t + dr;
       float* rp;
       if constexpr (MODE == MODE_DGRAD) {
-        const unsigned off = row_off[(wm * TM + mi) * 32 + 4 * h + dr];
+        const unsigned off = offs[mi][e];
         if (off == NO_ROW) continue;
         rp = tilep + off;
       } else {
@@ -993,10 +1023,21 @@ static inline void igemm_set_norm_bwd(IgemmParams& p, const VgNormBwdSrc& nb) {
   p.bact = nb.act; p.bslope = nb.slope;
 }
 
-// Waves per block of the variant that serves (bm, bn, va, vb, prec).
-static inline int igemm_waves(int bm, int bn, int va, int vb, int prec) {
+// Whether every factor of the kernels' address products is below 2^23 (the eight-wave f32 variants multiply with
+// v_mul_i32_i24): pixel counts of both tensors, weights per input / output channel, the extents of the GEMM.
+static inline bool igemm_small24(long long N, long long H, long long W, long long Ci, long long Co, long long KH,
+                                 long long KW, long long Ho, long long Wo, long long Ktot = 0, long long Ncols = 0) {
+  const long long lim = 1LL << 23;
+  return N * H * W < lim && N * Ho * Wo < lim && Co * KH * KW < lim && Ci * KH * KW < lim && Ktot < lim && Ncols < lim;
+}
+static inline bool igemm_small24(const IgemmParams& p) {
+  return igemm_small24(p.N, p.H, p.W, p.Ci, p.Co, p.KH, p.KW, p.Ho, p.Wo, p.Ktot, p.Ncols);
+}
+
+// Waves per block of the variant that serves (bm, bn, va, vb, prec); small24: igemm_small24 of the problem.
+static inline int igemm_waves(int bm, int bn, int va, int vb, int prec, bool small24) {
   const bool large = (bm == 128 && bn == 128) || (bm == 128 && bn == 64) || (bm == 64 && bn == 128);
-  return prec == PREC_F32 && va == 4 && vb == 4 && large ? 8 : 4;
+  return prec == PREC_F32 && va == 4 && vb == 4 && large && small24 ? 8 : 4;
 }
 
 // Launch one (BM, BN, VA, VB) variant chosen at run time; the wave arrangement follows the tile. prec = PREC_BF16 is
@@ -1014,7 +1055,7 @@ static inline int igemm_launch(const IgemmParams& p, int bm, int bn, int va, int
   // two blocks bring four waves to every SIMD instead of two; measured +2..10 % on the DCGAN layers)
   if (p.bx && !p.stats) {      // slope mask of an activation applied to the stored gradient
     if constexpr (MODE == MODE_DGRAD) {
-      if (igemm_waves(bm, bn, va, vb, prec) != 8) return -3;
+      if (igemm_waves(bm, bn, va, vb, prec, igemm_small24(p)) != 8) return -3;
       if (bm == 128 && bn == 128) vg_launch_timed(igemm_kernel<MODE, 128, 128, 2, B_MC, 4, 4, PREC_F32, 8, 3>, grid, dim3(512), 0, st, p);
       else if (bm == 128) vg_launch_timed(igemm_kernel<MODE, 128, 64, 4, B_MC, 4, 4, PREC_F32, 8, 3>, grid, dim3(512), 0, st, p);
       else vg_launch_timed(igemm_kernel<MODE, 64, 128, 2, B_MC, 4, 4, PREC_F32, 8, 3>, grid, dim3(512), 0, st, p);
@@ -1022,7 +1063,7 @@ static inline int igemm_launch(const IgemmParams& p, int bm, int bn, int va, int
     }
     return -3;
   }
-  if (igemm_waves(bm, bn, va, vb, prec) == 8 && p.stats) {
+  if (igemm_waves(bm, bn, va, vb, prec, igemm_small24(p)) == 8 && p.stats) {
     if constexpr (MODE != MODE_WGRAD) {
       if (p.bx) {
         if (bm == 128 && bn == 128) vg_launch_timed(igemm_kernel<MODE, 128, 128, 2, B_MC, 4, 4, PREC_F32, 8, 2>, grid, dim3(512), 0, st, p);
@@ -1037,7 +1078,7 @@ static inline int igemm_launch(const IgemmParams& p, int bm, int bn, int va, int
     }
   }
   if (p.stats) return -3;    // column statistics exist for the eight-wave f32 kernels only: the caller runs without them
-  if (igemm_waves(bm, bn, va, vb, prec) == 8) {
+  if (igemm_waves(bm, bn, va, vb, prec, igemm_small24(p)) == 8) {
     if (bm == 128 && bn == 128) vg_launch_timed(igemm_kernel<MODE, 128, 128, 2, B_MC, 4, 4, PREC_F32, 8>, grid, dim3(512), 0, st, p);
     else if (bm == 128) vg_launch_timed(igemm_kernel<MODE, 128, 64, 4, B_MC, 4, 4, PREC_F32, 8>, grid, dim3(512), 0, st, p);
     else vg_launch_timed(igemm_kernel<MODE, 64, 128, 2, B_MC, 4, 4, PREC_F32, 8>, grid, dim3(512), 0, st, p);
