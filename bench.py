@@ -106,7 +106,7 @@ def newest_pmc_summary():
 # the bandwidth-bound kernels of an iteration whose achieved HBM rate the line reports against the chip's peak
 HBM_KERNELS = ("bn_apply_kernel", "bn_bwd_apply_kernel", "bn_dbwd_apply_kernel", "act_bwd_kernel", "colreduce_partial",
                "gp_interp_kernel", "gp_rownorm_kernel", "gp_penalty_bwd_kernel", "rmsprop_multi_kernel",
-               "grad_sum_multi_kernel", "slab_reduce_kernel", "dgrad_scatter_kernel", "stem_fwd_kernel",
+               "grad_sum_multi_kernel", "slab_reduce_kernel", "dgrad_scatter42_kernel", "dgrad_scatter_kernel", "stem_fwd_kernel",
                "stem_wgrad_kernel")
 
 

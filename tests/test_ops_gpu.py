@@ -788,6 +788,26 @@ def test_kernel_timing_events_hold_the_kernels_own_duration(gpu):
 
 
 @pytest.mark.gpu
+def test_eight_wave_kernels_are_not_given_factors_beyond_24_bits(gpu):
+    """The eight-wave f32 contraction kernels form their address products with 24-bit multiplies; a problem with 2^23 or
+    more pixels (or any other factor that large) has to run on the four-wave variants, which multiply in 32 bits. The
+    library names the variant a geometry gets, and a forward convolution over 8.4 million input pixels agrees with torch."""
+    from vegans.engine import ops
+    small = ops.Geom(256, 32, 32, 64, 128, 4, 4, 2, 2, 1, 1)
+    assert ops.conv_variant(0, small).endswith("0, 8, 0>"), ops.conv_variant(0, small)
+    N, Ci, H, W, Co, k, s, p = 1, 8, 2900, 2900, 64, 4, 2, 1            # 8.41e6 input pixels >= 2^23
+    g = ops.Geom(N, H, W, Ci, Co, k, k, s, s, p, p)
+    assert N * H * W >= 1 << 23
+    assert ops.conv_variant(0, g) == "igemm_kernel<0, 128, 64, 2, false, 4, 4, 0, 4, 0>", ops.conv_variant(0, g)
+    gen = torch.Generator().manual_seed(3)
+    x = torch.randn(N, Ci, H, W, generator=gen)
+    w = torch.randn(Co, Ci, k, k, generator=gen) * 0.1
+    want = F.conv2d(x, w, None, stride=s, padding=p)
+    got = ops.conv2d(x.to(gpu), w.to(gpu), None, (s, s), (p, p))
+    _close(got, want, what="forward convolution over 2^23 pixels (four-wave variant)")
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("act,slope", [("relu", 0.0), ("lrelu", 0.2)])
 def test_bn_backward_mask_rebuilt_from_input_equals_mask_from_output(gpu, act, slope):
     """The norm's backward kernels rebuild the fused activation's slope mask from (x, mean, invstd, gamma, beta); the

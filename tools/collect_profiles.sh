@@ -3,7 +3,7 @@
 # statistics of the same command, and three counter passes (each in a run of its own) of a short eager run.
 # usage: bash tools/collect_profiles.sh <tag>      (run from the repository root; writes under gpurun_out/<tag>_*)
 set -e
-TAG=${1:-r2}
+TAG=${1:-r3}
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out
 export TMPDIR=/tmp
