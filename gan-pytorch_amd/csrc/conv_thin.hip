@@ -1042,8 +1042,8 @@ static int try_dgrad_scatter(const vg_conv_geom* g, const void* gy, const float*
   if (grid > 0x7fffffffLL) return 0;
   // the image-head shape (4 x 4, stride 2, 32 or 64 gradient channels, one tile across the width): persistent blocks
   if (taps == 16 && g->kh == 4 && g->sh == 2 && g->sw == 2 && bt_w == 1 && (g->Ci == 3 || g->Ci == 4) &&
-      (g->Co == 32 || g->Co == 64) && (g->W * g->Ci) % 4 == 0 && vg_aligned16(gx) &&
-      (long long)g->N * g->Ho * g->Wo * g->Co < 0x7fffffffLL && (long long)g->H * g->W * g->Ci * 2 < (1 << 22)) {
+      (g->Co == 32 || g->Co == 64) && (g->W * g->Ci) % 4 == 0 && g->W * g->Ci <= 1024 && vg_aligned16(gx) &&
+      (long long)g->N * g->Ho * g->Wo * g->Co < 0x7fffffffLL) {     // (a row of the image fits one gather pass: 256 lanes x 4 floats)
     int lg = 0;
     while ((1 << lg) < best_rw) ++lg;
     // two blocks per compute unit (what the kernel's registers allow), each walking every 512th tile: with the 1280
