@@ -47,6 +47,15 @@ CONV_CASES = [
     (2, 4, 37, 21, 32, 4, 2, 1),     # Ci=4, 32 channels, two row tiles, odd sizes
     (5, 3, 70, 40, 32, 4, 2, 0),     # no padding, five row tiles per image, more tiles than one pass of blocks may hold
     (2, 3, 66, 64, 64, 4, 2, 2),     # padding 2: 33 gradient columns in 64-wide tiles of 4 rows
+    # channel counts in multiples of 32 (the block-uniform k-walks of the contraction kernels) away from the DCGAN shapes
+    (2, 256, 15, 15, 512, 4, 1, 1),  # PatchGAN layer: stride 1, one parity class of 16 taps
+    (2, 128, 13, 11, 64, 3, 1, 1),   # 3x3 stride 1, odd sizes
+    (3, 64, 12, 12, 96, 5, 2, 2),    # 5x5 stride 2: classes with 9, 6, 6 and 4 taps
+    (4, 512, 2, 2, 512, 4, 2, 1),    # U-Net bottleneck: one output pixel per image
+    (2, 32, 40, 16, 64, 4, 2, 1),    # wgrad: k-steps of two whole output rows (Wo = 8: four rows of a 20-row image per k-step)
+    (40, 64, 8, 8, 128, 4, 2, 1),    # wgrad: a k-step covers two whole images (Ho = Wo = 4)
+    (2, 6, 20, 20, 64, 4, 2, 1),     # PatchGAN stem on a 6-channel pair: input gradient with 4-byte weight loads, 64 channels
+    (2, 64, 10, 10, 6, 3, 1, 1),     # 6 output channels: weight gradient and forward with 4-byte loads beside 64 input channels
     # the benchmark's own launches: DCGAN-64 critic layers at batch 256 (the split-K plan, grid sizes and slab set of
     # that batch; the other cases run at a few images)
     (256, 3, 64, 64, 64, 4, 2, 1),   # image stem: 262144 output pixels
@@ -223,6 +232,9 @@ CONVT_CASES = [
     (2, 16, 8, 8, 3, 4, 2, 1),      # image head, Cout=3
     (3, 8, 5, 7, 12, 3, 1, 1),      # stride 1
     (2, 20, 4, 4, 10, 5, 3, 1),     # stride 3, k=5: parity classes with different tap counts
+    (2, 512, 1, 1, 512, 4, 2, 1),   # U-Net innermost up-convolution: 1x1 -> 2x2, every class a single tap
+    (2, 256, 6, 5, 128, 4, 2, 1),   # channel counts in multiples of 32, odd sizes
+    (2, 64, 7, 7, 32, 3, 1, 1),     # stride 1, 3x3, one class of nine taps
     # the benchmark's own launches: DCGAN-64 generator layers at batch 256
     (256, 100, 1, 1, 512, 4, 1, 0),   # latent GEMM
     (256, 512, 4, 4, 256, 4, 2, 1),   # 4 classes x (4096 x 256 x 2048)
