@@ -108,6 +108,7 @@ static int conv_dgrad_impl(const vg_conv_geom* g, const float* gy, const float* 
   p.M = g->N * Hc * Wc;
   p.fast_div = p.M < (1 << 22) ? 1 : 0;
   p.Ktot = 0;  // per class, derived in the kernel
+  igemm_set_classes(p);
   const int bn = igemm_pick_bn(p.Ncols, precision);
   p.ntiles = (p.Ncols + bn - 1) / bn;
   const int bm = igemm_pick_bm(p.M, p.ntiles, g->sh * g->sw, bn, planes ? PREC_SPLIT : precision);

@@ -64,7 +64,38 @@ struct IgemmParams {
   const float *bx, *bmean, *binvstd, *bgamma, *bbeta;
   int bact;
   float bslope;
+  // dgrad: what a block needs to know about its parity class, worked out on the host for the first ncls classes (0: the
+  // kernel derives it, a dozen block-uniform integer divisions that the compiler runs on the vector ALU)
+  int ncls;
+  struct Class {
+    int cls_h, cls_w, off_h, off_w, Hc, Wc, nth, ntw, base_h, base_w;
+    float inv_roww, inv_plane, inv_ntw;
+  } cls[4];
 };
+
+// Fills p.cls for an input-gradient launch (strides whose sh * sw classes fit the table).
+static inline void igemm_set_classes(IgemmParams& p) {
+  p.ncls = 0;
+  if (p.sh * p.sw > 4) return;
+  for (int zz = 0; zz < p.sh * p.sw; ++zz) {
+    IgemmParams::Class& c = p.cls[zz];
+    c.cls_h = zz / p.sw;
+    c.cls_w = zz - c.cls_h * p.sw;
+    c.off_h = ((c.cls_h - p.ph) % p.sh + p.sh) % p.sh;
+    c.off_w = ((c.cls_w - p.pw) % p.sw + p.sw) % p.sw;
+    c.Hc = c.off_h < p.H ? (p.H - c.off_h + p.sh - 1) / p.sh : 0;
+    c.Wc = c.off_w < p.W ? (p.W - c.off_w + p.sw - 1) / p.sw : 0;
+    c.nth = c.cls_h < p.KH ? (p.KH - c.cls_h + p.sh - 1) / p.sh : 0;
+    c.ntw = c.cls_w < p.KW ? (p.KW - c.cls_w + p.sw - 1) / p.sw : 0;
+    c.base_h = (c.off_h + p.ph - c.cls_h) / p.sh;
+    c.base_w = (c.off_w + p.pw - c.cls_w) / p.sw;
+    const int plane = c.Hc * c.Wc;
+    c.inv_roww = c.Wc > 0 ? 1.0f / (float)c.Wc : 0.f;
+    c.inv_plane = plane > 0 ? 1.0f / (float)plane : 0.f;
+    c.inv_ntw = c.ntw > 0 ? 1.0f / (float)c.ntw : 0.f;
+  }
+  p.ncls = p.sh * p.sw;
+}
 
 // Operand sizes for the kernel's range-checked loads; -1 when an operand cannot be addressed with a 31-bit byte offset.
 static inline int igemm_set_operands(IgemmParams& p, long long a_elems, long long b_elems) {
@@ -151,14 +182,24 @@ __global__ void __launch_bounds__(NW * 64, NW == 8 ? 4 : 1) igemm_kernel(const I
     const int id = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + (lin >> 3);
     int t;
     if constexpr (MODE == MODE_DGRAD) {   // the parity classes of one row tile read the same gradient pixels: keep them together
-      t = id / (int)gridDim.z;
-      zz = id - t * (int)gridDim.z;
+      if (gridDim.z == 4) {
+        t = id >> 2;
+        zz = id & 3;
+      } else {
+        t = id / (int)gridDim.z;
+        zz = id - t * (int)gridDim.z;
+      }
     } else {
       zz = id / tiles;
       t = id - zz * tiles;
     }
-    mt = t / p.ntiles;
-    nt = t - mt * p.ntiles;
+    if (p.ntiles == 1) {
+      mt = t;
+      nt = 0;
+    } else {
+      mt = t / p.ntiles;
+      nt = t - mt * p.ntiles;
+    }
   }
   const int m0 = mt * BM, n0 = nt * BN;
 
@@ -167,17 +208,26 @@ __global__ void __launch_bounds__(NW * 64, NW == 8 ? 4 : 1) igemm_kernel(const I
   int kbeg = 0, kend = p.Ktot;
   // dgrad parity class
   int cls_h = 0, cls_w = 0, off_h = 0, off_w = 0, Hc = 0, Wc = 0, nth = 0, ntw = 0, base_h = 0, base_w = 0;
+  float tab_inv_roww = 0.f, tab_inv_plane = 0.f, tab_inv_ntw = 0.f;
+  const bool tab = MODE == MODE_DGRAD && zz < p.ncls;        // the host has worked this class out
   if constexpr (MODE == MODE_DGRAD) {
-    cls_h = zz / p.sw;
-    cls_w = zz - cls_h * p.sw;
-    off_h = ((cls_h - p.ph) % p.sh + p.sh) % p.sh;
-    off_w = ((cls_w - p.pw) % p.sw + p.sw) % p.sw;
-    Hc = off_h < p.H ? (p.H - off_h + p.sh - 1) / p.sh : 0;
-    Wc = off_w < p.W ? (p.W - off_w + p.sw - 1) / p.sw : 0;
-    nth = cls_h < p.KH ? (p.KH - cls_h + p.sh - 1) / p.sh : 0;
-    ntw = cls_w < p.KW ? (p.KW - cls_w + p.sw - 1) / p.sw : 0;
-    base_h = (off_h + p.ph - cls_h) / p.sh;
-    base_w = (off_w + p.pw - cls_w) / p.sw;
+    if (tab) {
+      const IgemmParams::Class& c = p.cls[zz];
+      cls_h = c.cls_h; cls_w = c.cls_w; off_h = c.off_h; off_w = c.off_w; Hc = c.Hc; Wc = c.Wc;
+      nth = c.nth; ntw = c.ntw; base_h = c.base_h; base_w = c.base_w;
+      tab_inv_roww = c.inv_roww; tab_inv_plane = c.inv_plane; tab_inv_ntw = c.inv_ntw;
+    } else {
+      cls_h = zz / p.sw;
+      cls_w = zz - cls_h * p.sw;
+      off_h = ((cls_h - p.ph) % p.sh + p.sh) % p.sh;
+      off_w = ((cls_w - p.pw) % p.sw + p.sw) % p.sw;
+      Hc = off_h < p.H ? (p.H - off_h + p.sh - 1) / p.sh : 0;
+      Wc = off_w < p.W ? (p.W - off_w + p.sw - 1) / p.sw : 0;
+      nth = cls_h < p.KH ? (p.KH - cls_h + p.sh - 1) / p.sh : 0;
+      ntw = cls_w < p.KW ? (p.KW - cls_w + p.sw - 1) / p.sw : 0;
+      base_h = (off_h + p.ph - cls_h) / p.sh;
+      base_w = (off_w + p.pw - cls_w) / p.sw;
+    }
     M = p.N * Hc * Wc;
     Ktot = nth * ntw * p.Co;
     kend = Ktot;
@@ -212,7 +262,14 @@ __global__ void __launch_bounds__(NW * 64, NW == 8 ? 4 : 1) igemm_kernel(const I
   const bool fast = p.fast_div != 0;
   const int roww = (MODE == MODE_FWD) ? p.Wo : Wc;
   const int plane = (MODE == MODE_FWD) ? p.Ho * p.Wo : Hc * Wc;
-  const float inv_roww = roww > 0 ? 1.0f / (float)roww : 0.f, inv_plane = plane > 0 ? 1.0f / (float)plane : 0.f;
+  float inv_roww, inv_plane;
+  if (tab) {
+    inv_roww = tab_inv_roww;
+    inv_plane = tab_inv_plane;
+  } else {
+    inv_roww = roww > 0 ? 1.0f / (float)roww : 0.f;
+    inv_plane = plane > 0 ? 1.0f / (float)plane : 0.f;
+  }
   if constexpr (!A_MC) {
 #pragma unroll
     for (int i = 0; i < RA; ++i) {
@@ -279,7 +336,9 @@ __global__ void __launch_bounds__(NW * 64, NW == 8 ? 4 : 1) igemm_kernel(const I
   int ak_c = 0, ak_t = 0;
   const int a_cch = (MODE == MODE_FWD) ? p.Ci : p.Co;
   const int a_steps = BK / a_cch, a_rem = BK - a_steps * a_cch;   // one k-step = a_steps whole taps + a_rem channels
-  const float inv_ntw = ntw > 0 ? 1.0f / (float)ntw : 0.f;
+  float inv_ntw;
+  if (tab) inv_ntw = tab_inv_ntw;
+  else inv_ntw = ntw > 0 ? 1.0f / (float)ntw : 0.f;
   if constexpr (!A_MC && VA == 4) {
     if (!ua_fast) {
       const int k4 = kbeg + 4 * (tid & 7);
