@@ -123,6 +123,9 @@ static int conv_dgrad_impl(const vg_conv_geom* g, const float* gy, const float* 
     if (int e = pgemm_prepare(pp, gy, (long long)g->N * g->Ho * g->Wo * g->Co, w, (long long)g->Co * g->kh * g->kw * g->Ci,
                               np, workspace, workspace_bytes, (hipStream_t)stream, "vg_conv2d_dgrad", gy_planes, w_planes))
       return e;
+    if (io_h) {
+      if (int e = pgemm_set_out_h(pp, (long long)g->N * g->H * g->W * g->Ci, "vg_conv2d_dgrad")) return e;
+    }
     if (io_h && nb) {      // with the slope mask of the activation in front of the convolution (vg_conv2d_dgrad_h_actmask)
       pp.mask_ref = (const __bf16*)(const void*)nb->x;
       pp.mask_act = nb->act;

@@ -133,6 +133,9 @@ static int conv_fwd_impl(const vg_conv_geom* g, const float* x, const float* w, 
     if (int e = pgemm_prepare(pp, x, (long long)g->N * g->H * g->W * g->Ci, w, (long long)g->Co * p.Ktot, np, workspace,
                               workspace_bytes, (hipStream_t)stream, "vg_conv2d_fwd", x_planes, w_planes))
       return e;
+    if (io_h) {
+      if (int e = pgemm_set_out_h(pp, (long long)p.M * p.Ncols, "vg_conv2d_fwd")) return e;
+    }
     if ((io_h ? pgemm_launch<MODE_FWD, 1, true>(pp, bm, bn, grid, (hipStream_t)stream)
               : np == 3 ? pgemm_launch<MODE_FWD, 3>(pp, bm, bn, grid, (hipStream_t)stream)
                         : pgemm_launch<MODE_FWD, 1>(pp, bm, bn, grid, (hipStream_t)stream)) != 0)

@@ -33,6 +33,7 @@ struct PgemmParams {
   const __bf16* mask_ref;
   int mask_act;
   float mask_slope;
+  unsigned out_bytes;            // bf16 results: size of the result tensor in bytes (below 2 GiB: pgemm_set_out_h)
 };
 
 static __device__ __attribute__((aligned(16))) unsigned int vg_zero_page_u[4] = {0u, 0u, 0u, 0u};  // never written
@@ -52,7 +53,17 @@ typedef short s16x4 __attribute__((ext_vector_type(4)));
 // Single-plane forward / input-gradient instances are held to 128 registers (four waves per SIMD, i.e. two 8-wave blocks
 // per CU: the 128 x 128 tile otherwise takes 136-146 and runs one block per CU; measured 25.7 vs 28.0 us and 28.4 vs
 // 31.9 us). Not the weight gradient: its grid is one block per CU anyway and the few spills cost it 15%.
-template <int MODE, int BM, int BN, int WAVES_M, int NP, int NW, int BK_ = 32, bool OUT_H = false, bool MASKED = false>
+// KU ("k-steps uniform", forward and input gradient): every k-step lies inside one filter tap (the channel count along k
+// is a multiple of BK) and a tap index fits a 32-bit mask (pgemm_uniform_k vouches for both). The walk over taps and
+// channels is then block-uniform and lives in scalar registers; a thread keeps, per tile row, a byte offset and a mask
+// of the taps that read inside the tensor, per weight unit a byte offset, and a load's address is one addition. Vector
+// instructions do not overlap the matrix instructions of a SIMD, so the fifty-odd of the general walk cost a k-step as
+// much as its MFMAs.
+// KU, weight gradient (k = gradient pixels): a k-step is whole rows of the gradient image (BK a multiple of Wo), its
+// rows lie in one image or are whole images, and every chunk is whole k-steps. Image and first row of a k-step are
+// then block-uniform; what a thread adds (its row inside the step, its column, its tap) never changes.
+template <int MODE, int BM, int BN, int WAVES_M, int NP, int NW, int BK_ = 32, bool OUT_H = false, bool MASKED = false,
+          bool KU = false>
 __global__ void __launch_bounds__(NW * 64, (NP == 1 && NW == 8 && MODE != MODE_WGRAD) ? 4 : 1) pgemm_kernel(const PgemmParams pp) {
   static_assert(!MASKED || (OUT_H && MODE == MODE_DGRAD), "the slope mask belongs to the input gradient on bf16 tensors");
   const IgemmParams& p = pp.g;
@@ -106,7 +117,15 @@ __global__ void __launch_bounds__(NW * 64, (NP == 1 && NW == 8 && MODE != MODE_W
   int M = p.M, Ktot = p.Ktot;
   int kbeg = 0, kend = p.Ktot;
   int cls_h = 0, cls_w = 0, off_h = 0, off_w = 0, Hc = 0, Wc = 0, nth = 0, ntw = 0, base_h = 0, base_w = 0;
+  float tab_inv_roww = 0.f, tab_inv_plane = 0.f, tab_inv_ntw = 0.f;
+  const bool tab = MODE == MODE_DGRAD && zz < p.ncls;     // the class's geometry as the host worked it out
   if constexpr (MODE == MODE_DGRAD) {
+   if (tab) {
+    const IgemmParams::Class& c = p.cls[zz];
+    cls_h = c.cls_h; cls_w = c.cls_w; off_h = c.off_h; off_w = c.off_w; Hc = c.Hc; Wc = c.Wc; nth = c.nth; ntw = c.ntw;
+    base_h = c.base_h; base_w = c.base_w;
+    tab_inv_roww = c.inv_roww; tab_inv_plane = c.inv_plane; tab_inv_ntw = c.inv_ntw;
+   } else {
     cls_h = zz / p.sw;
     cls_w = zz - cls_h * p.sw;
     off_h = ((cls_h - p.ph) % p.sh + p.sh) % p.sh;
@@ -117,6 +136,7 @@ __global__ void __launch_bounds__(NW * 64, (NP == 1 && NW == 8 && MODE != MODE_W
     ntw = cls_w < p.KW ? (p.KW - cls_w + p.sw - 1) / p.sw : 0;
     base_h = (off_h + p.ph - cls_h) / p.sh;
     base_w = (off_w + p.pw - cls_w) / p.sw;
+   }
     M = p.N * Hc * Wc;
     Ktot = nth * ntw * p.Co;
     kend = Ktot;
@@ -152,7 +172,10 @@ __global__ void __launch_bounds__(NW * 64, (NP == 1 && NW == 8 && MODE != MODE_W
   const bool fast = p.fast_div != 0;
   const int roww = (MODE == MODE_FWD) ? p.Wo : Wc;
   const int plane = (MODE == MODE_FWD) ? p.Ho * p.Wo : Hc * Wc;
-  const float inv_roww = roww > 0 ? 1.0f / (float)roww : 0.f, inv_plane = plane > 0 ? 1.0f / (float)plane : 0.f;
+  const float inv_roww = tab ? tab_inv_roww : roww > 0 ? 1.0f / (float)roww : 0.f;
+  const float inv_plane = tab ? tab_inv_plane : plane > 0 ? 1.0f / (float)plane : 0.f;
+  unsigned a_mask[(KU && !A_MC) ? UA : 1];      // KU: bit t set = tap t of this row reads inside the tensor
+  const int k8b = 16 * (tid % KV);              // KU: byte offset of the thread's 8 k inside a k-step of a [row][k] tile
   if constexpr (!A_MC) {
 #pragma unroll
     for (int i = 0; i < UA; ++i) {
@@ -172,6 +195,17 @@ __global__ void __launch_bounds__(NW * 64, (NP == 1 && NW == 8 && MODE != MODE_W
           a_w[i] = b + base_w;
           a_base[i] = (unsigned)((n * p.Ho + a_h[i]) * p.Wo + a_w[i]) * (unsigned)p.Co;
         }
+      }
+      if constexpr (KU) {
+        // taps (ta, tb), numbered ta * ntw + tb as the k-walk numbers them: which of them this row may read
+        const int tw = (MODE == MODE_FWD) ? p.KW : ntw, th = (MODE == MODE_FWD) ? p.KH : nth;
+        const unsigned lim_h = (unsigned)((MODE == MODE_FWD) ? p.H : p.Ho), lim_w = (unsigned)((MODE == MODE_FWD) ? p.W : p.Wo);
+        unsigned mw = 0u, mk = 0u;
+        for (int tb = 0; tb < tw; ++tb) mw |= ((unsigned)((MODE == MODE_FWD) ? a_w[i] + tb : a_w[i] - tb) < lim_w ? 1u : 0u) << tb;
+        for (int ta = 0; ta < th; ++ta)
+          mk |= ((unsigned)((MODE == MODE_FWD) ? a_h[i] + ta : a_h[i] - ta) < lim_h ? mw : 0u) << (ta * tw);
+        a_mask[i] = mk;                        // (a row past the end has a_h far below zero: no tap)
+        a_base[i] = a_base[i] * 2u + (unsigned)k8b;
       }
     }
   }
@@ -193,14 +227,14 @@ __global__ void __launch_bounds__(NW * 64, (NP == 1 && NW == 8 && MODE != MODE_W
   int ak_c = 0, ak_t = 0;
   const int a_cch = (MODE == MODE_FWD) ? p.Ci : p.Co;
   const int a_steps = BK / a_cch, a_rem = BK - a_steps * a_cch;
-  const float inv_ntw = ntw > 0 ? 1.0f / (float)ntw : 0.f;
-  if constexpr (!A_MC) {
+  const float inv_ntw = tab ? tab_inv_ntw : ntw > 0 ? 1.0f / (float)ntw : 0.f;
+  if constexpr (!A_MC && !KU) {
     const int k8 = kbeg + 8 * (tid % KV);
     ak_t = k8 / a_cch;
     ak_c = k8 - ak_t * a_cch;
   }
   int bk_co[(MODE == MODE_DGRAD) ? UB : 1], bk_t[(MODE == MODE_DGRAD) ? UB : 1];
-  if constexpr (MODE == MODE_DGRAD) {
+  if constexpr (MODE == MODE_DGRAD && !KU) {
 #pragma unroll
     for (int i = 0; i < UB; ++i) {
       const int k = kbeg + krowB(i);
@@ -221,10 +255,51 @@ __global__ void __launch_bounds__(NW * 64, (NP == 1 && NW == 8 && MODE != MODE_W
     for (int i = 0; i < UB; ++i) b_rowbase[i] = (unsigned)(n0 + rowB(i)) * (unsigned)Ktot;
   }
   const int khkw = p.KH * p.KW;
+  constexpr unsigned OOB = 0x80000000u;         // a byte offset no operand reaches (pgemm_prepare): the load returns zeros
+  // KU: the unit's byte offset at k-step 0 (tap 0, channel 0), OOB for a unit that is never read (adding the uniform
+  // part, below 2^31, leaves it out of range)
+  unsigned b_unit[KU ? UB : 1];
+  int s_c0 = 0, s_ta = 0, s_tb = 0, s_t = 0;    // KU: channel, tap row, tap column, tap number of the next k-step to load
+  if constexpr (KU && MODE == MODE_FWD) {
+#pragma unroll
+    for (int i = 0; i < UB; ++i)
+      b_unit[i] = (rowB(i) < BN && n0 + rowB(i) < p.Ncols) ? b_rowbase[i] * 2u + (unsigned)k8b : OOB;
+  }
+  if constexpr (KU && MODE == MODE_DGRAD) {
+#pragma unroll
+    for (int i = 0; i < UB; ++i)
+      b_unit[i] = (krowB(i) < BK && bn8 < p.Ncols) ? (unsigned)(krowB(i) * khkw * p.Ci + bn8) * 2u : OOB;
+  }
   int bp_row[(MODE == MODE_WGRAD) ? UB : 1], bp_wo[(MODE == MODE_WGRAD) ? UB : 1];
   const int w_steps = (MODE == MODE_WGRAD) ? BK / p.Wo : 0, w_rem = (MODE == MODE_WGRAD) ? BK - w_steps * p.Wo : 0;
   const float inv_ho = 1.0f / (float)p.Ho;
-  if constexpr (MODE == MODE_WGRAD) {
+  // KU weight gradient. Uniform: image s_n and row s_ho of the k-step's first pixel. Per B unit: wg_hic = what the
+  // unit adds to s_ho * sh to give its window row, wg_c = its byte offset relative to the window row s_ho * sh of
+  // image s_n (OOB where its column or tap column falls outside). Per A unit: its byte offset relative to the step's
+  // first pixel.
+  int wg_hic[(KU && MODE == MODE_WGRAD) ? UB : 1];
+  unsigned wg_c[(KU && MODE == MODE_WGRAD) ? UB : 1], wg_a[(KU && MODE == MODE_WGRAD) ? UA : 1];
+  int s_n = 0, s_ho = 0;
+  if constexpr (KU && MODE == MODE_WGRAD) {
+    const int row0 = kbeg / p.Wo;               // kbeg is a multiple of BK, BK of Wo
+    s_n = row0 / p.Ho;
+    s_ho = row0 - s_n * p.Ho;
+    const int wci = p.W * p.Ci;
+#pragma unroll
+    for (int i = 0; i < UB; ++i) {
+      const int j = krowB(i), dr = j / p.Wo, wo = j - dr * p.Wo;
+      const int dn = dr / p.Ho, dh = dr - dn * p.Ho;          // (dn = 0 unless the step spans whole images)
+      const int wi = wo * p.sw - p.pw + b_tb;
+      wg_hic[i] = dh * p.sh - p.ph + b_ta;
+      const bool ok = j < BK && (unsigned)wi < (unsigned)p.W;  // (b_ta is far below zero for a column past the end)
+      wg_c[i] = ok ? (unsigned)(((dn * p.H + wg_hic[i]) * p.W + wi) * p.Ci + b_ci) * 2u : OOB;
+      if (!ok) wg_hic[i] = -(1 << 28);
+    }
+    const int m8 = m0 + 8 * (tid % TPKA);
+#pragma unroll
+    for (int i = 0; i < UA; ++i) wg_a[i] = (krowA(i) < BK && m8 < p.Co) ? (unsigned)(krowA(i) * p.Co + m8) * 2u : OOB;
+  }
+  if constexpr (MODE == MODE_WGRAD && !KU) {
 #pragma unroll
     for (int i = 0; i < UB; ++i) {
       const int pix = kbeg + krowB(i);
@@ -240,7 +315,6 @@ __global__ void __launch_bounds__(NW * 64, (NP == 1 && NW == 8 && MODE != MODE_W
   // byte offset: a unit that must not be read gets an offset beyond the buffer and comes back as zeros (no 64-bit
   // address arithmetic and no pointer select in the k-walk; with bf16 MFMAs a k-step's address arithmetic on the vector
   // ALU takes as long as its matrix work).
-  constexpr unsigned OOB = 0x80000000u;
   const __amdgpu_buffer_rsrc_t rsrcA = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(pp.Ap), 0, (int)pp.a_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsrcB = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(pp.Bp), 0, (int)pp.b_bytes, 0x00020000);
   const unsigned a_pbytes = (unsigned)pp.a_plane * 2u, b_pbytes = (unsigned)pp.b_plane * 2u;
@@ -255,7 +329,63 @@ __global__ void __launch_bounds__(NW * 64, (NP == 1 && NW == 8 && MODE != MODE_W
     }
   };
 
+  auto ld_bytes = [&](const __amdgpu_buffer_rsrc_t& rs, unsigned pbytes, unsigned boff, u32x4 (&dst)[NP]) {
+#pragma unroll
+    for (int q = 0; q < NP; ++q) {
+      if constexpr ((PG_ABLATE & 1) != 0) {
+        dst[q] = u32x4{boff, 0u, 0u, 0u};
+      } else {
+        dst[q] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(boff + q * pbytes), 0, 0));
+      }
+    }
+  };
+
   auto load_tiles = [&](int st) {
+    if constexpr (KU && MODE == MODE_WGRAD) {
+      const int hrow = s_ho * p.sh;
+      const unsigned ub = (unsigned)((s_n * p.H + hrow) * p.W * p.Ci) * 2u, ua = (unsigned)kpos * (unsigned)p.Co * 2u;
+#pragma unroll
+      for (int i = 0; i < UA; ++i) ld_bytes(rsrcA, a_pbytes, wg_a[i] + ua, ra[st][i]);
+#pragma unroll
+      for (int i = 0; i < UB; ++i)
+        ld_bytes(rsrcB, b_pbytes, (unsigned)(hrow + wg_hic[i]) < (unsigned)p.H ? wg_c[i] + ub : OOB, rb[st][i]);
+      kpos += BK;
+      s_ho += w_steps;
+      if (s_ho >= p.Ho) {                       // the next step starts w_steps rows on: same image, or whole images on
+        s_n += w_steps > p.Ho ? w_steps / p.Ho : 1;
+        s_ho = 0;
+      }
+      return;
+    }
+    if constexpr (KU) {
+      // block-uniform part of the k-step: scalar registers
+      const unsigned bit = 1u << s_t;
+      unsigned ua, ub;
+      if constexpr (MODE == MODE_FWD) {
+        ua = (unsigned)((s_ta * p.W + s_tb) * p.Ci + s_c0) * 2u;
+        ub = (unsigned)kpos * 2u;
+      } else {
+        ua = (unsigned)(s_c0 - (s_ta * p.Wo + s_tb) * p.Co) * 2u;
+        ub = (unsigned)((s_c0 * khkw + (cls_h + p.sh * s_ta) * p.KW + cls_w + p.sw * s_tb) * p.Ci) * 2u;
+      }
+#pragma unroll
+      for (int i = 0; i < UA; ++i) ld_bytes(rsrcA, a_pbytes, (a_mask[i] & bit) ? a_base[i] + ua : OOB, ra[st][i]);
+#pragma unroll
+      for (int i = 0; i < UB; ++i) ld_bytes(rsrcB, b_pbytes, b_unit[i] + ub, rb[st][i]);
+      kpos += BK;
+      s_c0 += BK;
+      if (s_c0 >= a_cch) {
+        s_c0 = 0;
+        ++s_t;
+        ++s_tb;
+        const int tw = (MODE == MODE_FWD) ? p.KW : ntw;
+        if (s_tb >= tw) {
+          s_tb = 0;
+          ++s_ta;
+        }
+      }
+      return;
+    }
     const int kb = kpos;
     // ---------------- A ----------------
     if constexpr (!A_MC) {
@@ -550,66 +680,104 @@ __global__ void __launch_bounds__(NW * 64, (NP == 1 && NW == 8 && MODE != MODE_W
   }
   if constexpr (OUT_H) {
     static_assert(MODE != MODE_WGRAD, "weight gradients leave as f32 slabs");
-    const unsigned col_off = (unsigned)(n0 + wn * TN * 32 + (r & ~1));
-    __bf16* outh = reinterpret_cast<__bf16*>(p.out) + col_off;
+    // A lane holds column c = (lane & 31) of 16 rows; rows 2 e2 and 2 e2 + 1 of its accumulators are neighbours, and so
+    // are the columns of lanes l and l ^ 1. The even lane of a pair stores the first row's two columns as one word, the
+    // odd lane the second row's. Results leave through range-checked buffer stores on 32-bit byte offsets: a row past
+    // the end has an offset beyond the tensor (below 2 GiB: checked by the host) and its store is dropped, so the
+    // store loop carries no conditions; a lane whose columns lie past the last one sits the whole loop out.
     const bool odd = (lane & 1) != 0;
-    // rows of accumulators 2 e2 and 2 e2 + 1 are neighbours; the even lane stores the first, the odd lane the second.
-    // Element offsets of this lane's rows first (NO_ROW past the last row), and, for the MASKED form, all the words of
-    // the activation output it will need: loads issued inside the store loop would each be waited for before the store
-    // behind them, sixteen round trips in a row.
-    constexpr unsigned NO_ROW = 0xffffffffu;
-    unsigned roffs[TM][8];
+    const __amdgpu_buffer_rsrc_t rsrcO = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, (int)pp.out_bytes, 0x00020000);
+    const unsigned colb = 2u * (unsigned)(n0 + wn * TN * 32 + (r & ~1));
+    unsigned roffb[TM][8];                       // byte offsets of the rows this lane stores
     unsigned yy[MASKED ? TM : 1][MASKED ? 8 : 1][MASKED ? TN : 1];
+    if (has_bias) {
+#pragma unroll
+      for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < TN; ++ni)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) acc[mi][ni][e] += bcol[ni];
+    }
+    // Input gradient: a tile's rows are pixels of one parity class, scattered over the image. Each row's offset takes
+    // two divisions; it is worked out once per block and left in LDS (the k loop is done with it), not sixteen times
+    // per lane. Within a group of four rows the table is kept in the order 0, 2, 1, 3, so that a lane's two rows of a
+    // group (0 and 2 for an even lane, 1 and 3 for an odd one) are one 8-byte read.
+    unsigned* row_off = reinterpret_cast<unsigned*>(smem);
+    if constexpr (MODE == MODE_DGRAD) {
+      static_assert(NT >= BM, "one table entry per thread");
+      __syncthreads();                          // every wave is done with the staged tiles
+      if (tid < BM) {
+        const int row = m0 + tid;
+        unsigned roff = OOB;
+        if (row < M) {
+          const int n = vg_div_row(row, plane, inv_plane, fast), rem = row - n * plane;
+          const int ii = vg_div_row(rem, roww, inv_roww, fast), jj = rem - ii * roww;
+          roff = (unsigned)((n * p.H + ii * p.sh + off_h) * p.W + jj * p.sw + off_w) * (unsigned)p.Ncols * 2u;
+        }
+        row_off[(tid & ~3) | ((tid & 1) << 1) | ((tid >> 1) & 1)] = roff;
+      }
+      __syncthreads();
+    }
 #pragma unroll
     for (int mi = 0; mi < TM; ++mi) {
-      const int row_t = m0 + (wm * TM + mi) * 32 + 4 * h;
+      if constexpr (MODE == MODE_DGRAD) {
 #pragma unroll
-      for (int e2 = 0; e2 < 8; ++e2) {
-        const int dr = ((2 * e2) & 3) + 8 * ((2 * e2) >> 2) + (odd ? 1 : 0);
-        const int row = row_t + dr;
-        unsigned roff = NO_ROW;
-        if (row < M) {
-          if constexpr (MODE == MODE_DGRAD) {
-            const int n = vg_div_row(row, plane, inv_plane, fast), rem = row - n * plane;
-            const int ii = vg_div_row(rem, roww, inv_roww, fast), jj = rem - ii * roww;
-            roff = (unsigned)((n * p.H + ii * p.sh + off_h) * p.W + jj * p.sw + off_w) * (unsigned)p.Ncols;
-          } else {
-            roff = (unsigned)row * (unsigned)p.Ncols;
-          }
+        for (int q = 0; q < 4; ++q) {
+          const uint2 t = *reinterpret_cast<const uint2*>(&row_off[(wm * TM + mi) * 32 + 4 * h + 8 * q + (odd ? 2 : 0)]);
+          roffb[mi][2 * q] = t.x;
+          roffb[mi][2 * q + 1] = t.y;
         }
-        roffs[mi][e2] = roff;
-        if constexpr (MASKED) {
+      } else {
+        const int row_t = m0 + (wm * TM + mi) * 32 + 4 * h + (odd ? 1 : 0);
+        const unsigned rowb = 2u * (unsigned)p.Ncols;
 #pragma unroll
-          for (int ni = 0; ni < TN; ++ni)
-            yy[mi][e2][ni] = (roff != NO_ROW && cok[ni])
-                                 ? *reinterpret_cast<const unsigned int*>(pp.mask_ref + col_off + roff + ni * 32) : 0u;
+        for (int e2 = 0; e2 < 8; ++e2) {
+          const int row = row_t + ((2 * e2) & 3) + 8 * ((2 * e2) >> 2);
+          roffb[mi][e2] = row < M ? (unsigned)row * rowb : OOB;
         }
       }
     }
+    if constexpr (MASKED) {
+      // the words of the activation's output behind the words this lane stores, all requested before the first is used
+      const __amdgpu_buffer_rsrc_t rsrcM =
+          __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(pp.mask_ref), 0, (int)pp.out_bytes, 0x00020000);
+#pragma unroll
+      for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+        for (int e2 = 0; e2 < 8; ++e2)
+#pragma unroll
+          for (int ni = 0; ni < TN; ++ni)
+            yy[mi][e2][ni] = cok[ni] ? (unsigned)__builtin_amdgcn_raw_buffer_load_b32(rsrcM, (int)(roffb[mi][e2] + colb + ni * 64), 0, 0) : 0u;
+    }
     const float low = pp.mask_act == VG_ACT_RELU ? 0.f : pp.mask_slope;
+    const unsigned sel = odd ? 0x03020706u : 0x05040100u;   // v_perm_b32(neighbour, own): (neighbour, own) high halves / (own, neighbour) low halves
 #pragma unroll
-    for (int mi = 0; mi < TM; ++mi) {
+    for (int ni = 0; ni < TN; ++ni) {
+      if (cok[ni]) {                             // (the lanes of a pair agree: column counts are multiples of 8)
 #pragma unroll
-      for (int e2 = 0; e2 < 8; ++e2) {
-        const unsigned roff = roffs[mi][e2];
+        for (int mi = 0; mi < TM; ++mi) {
 #pragma unroll
-        for (int ni = 0; ni < TN; ++ni) {
-          float v0 = acc[mi][ni][2 * e2], v1 = acc[mi][ni][2 * e2 + 1];
-          if (has_bias) {
-            v0 += bcol[ni];
-            v1 += bcol[ni];
+          for (int e2 = 0; e2 < 8; ++e2) {
+            const float v0 = acc[mi][ni][2 * e2], v1 = acc[mi][ni][2 * e2 + 1];
+            unsigned word;
+            if constexpr (MASKED) {
+              // the slope is applied to the f32 value at the position it is stored at: values change lanes first
+              const float keep = odd ? v1 : v0, send = odd ? v0 : v1;
+              const float recv = __builtin_bit_cast(
+                  float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, send), 0xB1, 0xF, 0xF, false));   // lane ^ 1
+              f32x2 pr = {odd ? recv : keep, odd ? keep : recv};
+              pr[0] *= __builtin_bit_cast(float, yy[mi][e2][ni] << 16) > 0.f ? 1.f : low;
+              pr[1] *= __builtin_bit_cast(float, yy[mi][e2][ni] & 0xffff0000u) > 0.f ? 1.f : low;
+              word = __builtin_bit_cast(unsigned int, __builtin_convertvector(pr, bf16x2));
+            } else {
+              // round both rows of the own column, fetch the neighbour's pair, keep the halves of this lane's row
+              const f32x2 own2 = {v0, v1};
+              const unsigned own = __builtin_bit_cast(unsigned int, __builtin_convertvector(own2, bf16x2));
+              const unsigned nbr = (unsigned)__builtin_amdgcn_update_dpp(0, (int)own, 0xB1, 0xF, 0xF, false);     // lane ^ 1
+              word = __builtin_amdgcn_perm(nbr, own, sel);
+            }
+            __builtin_amdgcn_raw_buffer_store_b32(word, rsrcO, (int)(roffb[mi][e2] + colb + ni * 64), 0, 0);
           }
-          const float keep = odd ? v1 : v0, send = odd ? v0 : v1;
-          const float recv = __builtin_bit_cast(
-              float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, send), 0xB1, 0xF, 0xF, false));   // lane ^ 1
-          f32x2 pr = {odd ? recv : keep, odd ? keep : recv};
-          if constexpr (MASKED) {       // the activation's output at the two positions this lane stores: positive -> slope 1
-            pr[0] *= __builtin_bit_cast(float, yy[mi][e2][ni] << 16) > 0.f ? 1.f : low;
-            pr[1] *= __builtin_bit_cast(float, yy[mi][e2][ni] & 0xffff0000u) > 0.f ? 1.f : low;
-          }
-          if (roff != NO_ROW && cok[ni])
-            *reinterpret_cast<unsigned int*>(outh + roff + ni * 32) =
-                __builtin_bit_cast(unsigned int, __builtin_convertvector(pr, bf16x2));
         }
       }
     }
@@ -646,16 +814,41 @@ __global__ void __launch_bounds__(NW * 64, (NP == 1 && NW == 8 && MODE != MODE_W
   }
 }
 
-// Tiles served: 128x128, 128x64, 64x128 (eight waves) and 64x64 (four waves).
-template <int MODE, int NP, bool OUT_H = false, bool MASKED = false>
-static inline int pgemm_launch(const PgemmParams& pp, int bm, int bn, dim3 grid, hipStream_t st) {
+// Result tensor of a launch that stores bf16 (`elements` of them): its size for the range-checked stores.
+static inline int pgemm_set_out_h(PgemmParams& pp, long long elements, const char* who) {
+  if (elements * 2 >= (1LL << 31))
+    return vg_fail(VG_ERR_INVALID, "%s: the bf16 kernels store through 31-bit byte offsets; the result is 2 GiB or larger", who);
+  pp.out_bytes = (unsigned)(elements * 2);
+  return 0;
+}
+
+// True when a forward / input-gradient launch may run the KU form of the kernel with k-steps of `bk`.
+static inline bool pgemm_uniform_k(int mode, const IgemmParams& p, int bk) {
+  if (mode == MODE_FWD) return p.Ci % bk == 0 && p.KH * p.KW <= 32;
+  if (mode == MODE_DGRAD) return p.Co % bk == 0 && ((p.KH + p.sh - 1) / p.sh) * ((p.KW + p.sw - 1) / p.sw) <= 32;
+  if (p.Wo <= 0 || bk % p.Wo != 0) return false;
+  const int rows = bk / p.Wo;                   // gradient rows per k-step
+  return (p.Ho % rows == 0 || rows % p.Ho == 0) && p.Ktot % bk == 0 && p.kchunk % bk == 0;
+}
+
+// Tiles served: 128x128, 128x64, 64x128 (eight waves) and 64x64 (four waves). The KU form exists for one plane: the
+// forward and input-gradient kernels with bf16 results and the weight gradient.
+template <int MODE, int NP, bool OUT_H, bool MASKED, bool KU>
+static inline int pgemm_launch_ku(const PgemmParams& pp, int bm, int bn, dim3 grid, hipStream_t st) {
   constexpr int BK = NP == 1 ? 64 : 32;     // a single plane leaves room for 64-deep tiles: half the barriers per flop
-  if (bm == 128 && bn == 128) vg_launch_timed(pgemm_kernel<MODE, 128, 128, 2, NP, 8, BK, OUT_H, MASKED>, grid, dim3(512), 0, st, pp);
-  else if (bm == 128 && bn == 64) vg_launch_timed(pgemm_kernel<MODE, 128, 64, 4, NP, 8, BK, OUT_H, MASKED>, grid, dim3(512), 0, st, pp);
-  else if (bm == 64 && bn == 128) vg_launch_timed(pgemm_kernel<MODE, 64, 128, 2, NP, 8, BK, OUT_H, MASKED>, grid, dim3(512), 0, st, pp);
-  else if (bm == 64 && bn == 64) vg_launch_timed(pgemm_kernel<MODE, 64, 64, 2, NP, 4, BK, OUT_H, MASKED>, grid, dim3(256), 0, st, pp);
+  if (bm == 128 && bn == 128) vg_launch_timed(pgemm_kernel<MODE, 128, 128, 2, NP, 8, BK, OUT_H, MASKED, KU>, grid, dim3(512), 0, st, pp);
+  else if (bm == 128 && bn == 64) vg_launch_timed(pgemm_kernel<MODE, 128, 64, 4, NP, 8, BK, OUT_H, MASKED, KU>, grid, dim3(512), 0, st, pp);
+  else if (bm == 64 && bn == 128) vg_launch_timed(pgemm_kernel<MODE, 64, 128, 2, NP, 8, BK, OUT_H, MASKED, KU>, grid, dim3(512), 0, st, pp);
+  else if (bm == 64 && bn == 64) vg_launch_timed(pgemm_kernel<MODE, 64, 64, 2, NP, 4, BK, OUT_H, MASKED, KU>, grid, dim3(256), 0, st, pp);
   else return -1;
   return 0;
+}
+template <int MODE, int NP, bool OUT_H = false, bool MASKED = false>
+static inline int pgemm_launch(const PgemmParams& pp, int bm, int bn, dim3 grid, hipStream_t st) {
+  if constexpr (NP == 1 && (OUT_H || MODE == MODE_WGRAD)) {
+    if (pgemm_uniform_k(MODE, pp.g, 64)) return pgemm_launch_ku<MODE, NP, OUT_H, MASKED, true>(pp, bm, bn, grid, st);
+  }
+  return pgemm_launch_ku<MODE, NP, OUT_H, MASKED, false>(pp, bm, bn, grid, st);
 }
 
 // conv_planes.hip

@@ -21,7 +21,9 @@ SHAPES = [(256, 32, 32, 64, 128), (256, 16, 16, 128, 256), (256, 8, 8, 256, 512)
 
 
 def main():
-    reps = 200
+    # PG_ONLY="fwd:128" restricts the run to one contraction (mode:Ci), PG_REPS sets the repetitions (counter passes)
+    reps = int(os.environ.get("PG_REPS", "200"))
+    only = os.environ.get("PG_ONLY", "")
     out = []
     lib = _hip.load()
     st = _hip._stream()
@@ -43,7 +45,9 @@ def main():
                "dgrad": lambda: _hip.call("vg_conv2d_dgrad_h", G, P(gy), P(w), None, P(gx), st),
                "wgrad": lambda: _hip.call("vg_conv2d_wgrad_partial_h", G, P(gy), P(x), P(gw), P(ws), ctypes.c_size_t(nbytes), st)}
         for mode, fn in fns.items():
-            for _ in range(300):
+            if only and only != "%s:%d" % (mode, Ci):
+                continue
+            for _ in range(300 if not only else 3):
                 fn()
             torch.cuda.synchronize()
             start, stop = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
