@@ -65,6 +65,13 @@ H_CONV_CASES = [
     (5, 40, 6, 6, 72, 3, 2, 0),        # channel counts that are multiples of 8 only, unequal parity classes
     (130, 64, 4, 4, 40, 1, 1, 0),      # 1x1, rows not a tile multiple, ragged column tile
     (2, 128, 8, 8, 256, 4, 2, 1),
+    # k-steps inside one tap (channel counts in multiples of 64) and weight-gradient k-steps of whole gradient rows:
+    (2, 64, 9, 7, 128, 3, 1, 1),       # nine taps with padding on every side, ragged rows; stride-1 input gradient
+    (3, 64, 9, 11, 64, 5, 2, 2),       # 25 taps; parity classes with 3x3, 3x2, 2x3 and 2x2 taps
+    (4, 8, 24, 32, 64, 3, 2, 1),       # 12 x 16 gradient: four rows per k-step, three k-steps per image
+    (48, 64, 4, 4, 64, 3, 2, 1),       # 2 x 2 gradient: sixteen images per k-step
+    (2, 16, 64, 64, 64, 3, 1, 1),      # 64-wide gradient: one row per k-step
+    (1, 128, 32, 32, 64, 4, 2, 1),
 ]
 
 
