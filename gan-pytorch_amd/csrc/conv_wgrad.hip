@@ -16,7 +16,8 @@ struct WgradPlan {
 // target_blocks: how many blocks the split along k aims at. Two per CU for the f32 kernels (matrix-core-bound: the
 // second block hides the first one's stalls); one per CU for the contraction on bf16 tensors, which is bound by memory
 // traffic and gains more from halving its slab writes (measured: 512 better in f32, 256 better on bf16 tensors).
-WgradPlan wgrad_plan(const vg_conv_geom* g, int target_blocks = 512) {
+// kalign: what a split's k extent is rounded up to (the k-step of the kernel that will run it).
+WgradPlan wgrad_plan(const vg_conv_geom* g, int target_blocks = 512, int kalign = 32) {
   WgradPlan pl;
   pl.M = g->Co;
   pl.Ncols = g->kh * g->kw * g->Ci;
@@ -35,7 +36,7 @@ WgradPlan wgrad_plan(const vg_conv_geom* g, int target_blocks = 512) {
   if (ns < 1) ns = 1;
   if (ns > 1024) ns = 1024;
   int kchunk = (pl.Ktot + ns - 1) / ns;
-  kchunk = ((kchunk + 31) / 32) * 32;
+  kchunk = ((kchunk + kalign - 1) / kalign) * kalign;
   pl.kchunk = kchunk;
   pl.nsplit = (pl.Ktot + kchunk - 1) / kchunk;
   return pl;
@@ -168,17 +169,20 @@ extern "C" int vg_conv2d_wgrad_partial_h(const vg_conv_geom* g, const void* gy, 
 }
 
 constexpr int kTargetBlocksH = 256;
+// the plan of the contraction on bf16 tensors: 64-deep k-steps (measured again with the register-lean uniform k-walk,
+// which would fit two blocks per CU: 3.19-3.20 ms per iteration at 256 blocks, 3.27 at 384, 3.27-3.29 at 512)
+static WgradPlan wgrad_plan_h(const vg_conv_geom* g) { return wgrad_plan(g, kTargetBlocksH, 64); }
 
 extern "C" size_t vg_conv2d_wgrad_h_workspace_bytes(const vg_conv_geom* g) {
   if (vg_check_geom(g, "vg_conv2d_wgrad_h_workspace_bytes")) return 0;
-  const WgradPlan pl = wgrad_plan(g, kTargetBlocksH);
+  const WgradPlan pl = wgrad_plan_h(g);
   if (pl.nsplit <= 1) return 0;
   return (size_t)pl.nsplit * pl.M * pl.Ncols * sizeof(float);
 }
 
 extern "C" int vg_conv2d_wgrad_reduce_h(const vg_conv_geom* g, float* gw, const void* workspace, void* stream) {
   if (int e = vg_check_geom(g, "vg_conv2d_wgrad_reduce_h")) return e;
-  const WgradPlan pl = wgrad_plan(g, kTargetBlocksH);
+  const WgradPlan pl = wgrad_plan_h(g);
   if (pl.nsplit <= 1) return VG_OK;
   VG_REQUIRE(gw && workspace, "vg_conv2d_wgrad_reduce_h: null pointer");
   launch_slab_reduce((const float*)workspace, gw, (size_t)pl.M * pl.Ncols, pl.nsplit, (hipStream_t)stream);
@@ -193,7 +197,7 @@ static int wgrad_partial_impl(const vg_conv_geom* g, const float* gy, const floa
   if (precision < VG_PREC_F32 || precision > VG_PREC_F32_SPLIT)
     return vg_fail(VG_ERR_INVALID, "vg_conv2d_wgrad: unknown precision %d", precision);
   VG_REQUIRE(gy && x && gw, "vg_conv2d_wgrad: null tensor pointer");
-  const WgradPlan pl = io_h ? wgrad_plan(g, kTargetBlocksH) : wgrad_plan(g);
+  const WgradPlan pl = io_h ? wgrad_plan_h(g) : wgrad_plan(g);
   const size_t need = pl.nsplit > 1 ? (size_t)pl.nsplit * pl.M * pl.Ncols * sizeof(float) : 0;
   if (need > 0 && (!workspace || workspace_bytes < need || !vg_aligned16(workspace)))
     return vg_fail(VG_ERR_WORKSPACE, "vg_conv2d_wgrad: workspace of %zu bytes (16-byte aligned) required, got %zu",
