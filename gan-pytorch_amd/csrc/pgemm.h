@@ -52,7 +52,9 @@ typedef short s16x4 __attribute__((ext_vector_type(4)));
 // so that every lane stores a packed pair of columns: 4-byte stores, 16 lanes per 64-byte row segment.
 // Single-plane forward / input-gradient instances are held to 128 registers (four waves per SIMD, i.e. two 8-wave blocks
 // per CU: the 128 x 128 tile otherwise takes 136-146 and runs one block per CU; measured 25.7 vs 28.0 us and 28.4 vs
-// 31.9 us). Not the weight gradient: its grid is one block per CU anyway and the few spills cost it 15%.
+// 31.9 us). Not the weight gradient: its grid is one block per CU anyway and the few spills cost it 15%. Nor the input
+// gradient with the general k-walk, whose per-unit tap state no longer fits: under the bound it spills a staged
+// tile inside the loop (77 against 74 us on a 128 -> 160 channel layer).
 // KU ("k-steps uniform", forward and input gradient): every k-step lies inside one filter tap (the channel count along k
 // is a multiple of BK) and a tap index fits a 32-bit mask (pgemm_uniform_k vouches for both). The walk over taps and
 // channels is then block-uniform and lives in scalar registers; a thread keeps, per tile row, a byte offset and a mask
@@ -64,7 +66,7 @@ typedef short s16x4 __attribute__((ext_vector_type(4)));
 // then block-uniform; what a thread adds (its row inside the step, its column, its tap) never changes.
 template <int MODE, int BM, int BN, int WAVES_M, int NP, int NW, int BK_ = 32, bool OUT_H = false, bool MASKED = false,
           bool KU = false>
-__global__ void __launch_bounds__(NW * 64, (NP == 1 && NW == 8 && MODE != MODE_WGRAD) ? 4 : 1) pgemm_kernel(const PgemmParams pp) {
+__global__ void __launch_bounds__(NW * 64, (NP == 1 && NW == 8 && MODE != MODE_WGRAD && (KU || MODE == MODE_FWD)) ? 4 : 1) pgemm_kernel(const PgemmParams pp) {
   static_assert(!MASKED || (OUT_H && MODE == MODE_DGRAD), "the slope mask belongs to the input gradient on bf16 tensors");
   const IgemmParams& p = pp.g;
   constexpr int NT = NW * 64;

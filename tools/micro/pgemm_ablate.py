@@ -24,12 +24,15 @@ def main():
     # PG_ONLY="fwd:128" restricts the run to one contraction (mode:Ci), PG_REPS sets the repetitions (counter passes)
     reps = int(os.environ.get("PG_REPS", "200"))
     only = os.environ.get("PG_ONLY", "")
+    shapes = SHAPES
+    if os.environ.get("PG_SHAPES"):          # "N,H,W,Ci,Co;N,H,W,Ci,Co": other 4x4 stride-2 layers
+        shapes = [tuple(int(v) for v in t.split(",")) for t in os.environ["PG_SHAPES"].split(";")]
     out = []
     lib = _hip.load()
     st = _hip._stream()
     P = lambda t: ctypes.c_void_p(t.data_ptr())
     CL = torch.channels_last
-    for (N, H, W, Ci, Co) in SHAPES:
+    for (N, H, W, Ci, Co) in shapes:
         k, s, p = 4, 2, 1
         g = ops.Geom(N, H, W, Ci, Co, k, k, s, s, p, p)
         G = ctypes.byref(g.c)
