@@ -382,7 +382,8 @@ int vg_clamp(float* param, size_t n, float lo, float hi, void* stream);
  * tensors (channel counts in multiples of 8, more than 32 GEMM columns, not one of the thin / stem / 1x1 special
  * kernels); other shapes go through the f32 entry points on converted copies. No workspace except the split-K slabs
  * of the weight gradient (vg_conv2d_wgrad_h_workspace_bytes, fewer and longer splits than the f32 plan;
- * vg_conv2d_wgrad_reduce_h adds them in split order). */
+ * vg_conv2d_wgrad_reduce_h adds them in split order). Every tensor handed to these entry points is addressed through
+ * 31-bit byte offsets: an operand or a bf16 result of 2 GiB or more is refused with VG_ERR_INVALID. */
 int vg_conv2d_h_applies(int mode, const vg_conv_geom* g);
 int vg_conv2d_fwd_h(const vg_conv_geom* g, const void* x, const void* w, const float* bias, void* y, void* stream);
 int vg_conv2d_dgrad_h(const vg_conv_geom* g, const void* gy, const void* w, const float* bias, void* gx, void* stream);

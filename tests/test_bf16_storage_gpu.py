@@ -131,6 +131,23 @@ def test_h_entry_points_refuse_shapes_they_do_not_serve(gpu):
         assert b"not served" in lib.vg_last_error()
 
 
+def test_h_forward_refuses_a_result_of_two_gib(gpu):
+    """The bf16 kernels store through range-checked 31-bit byte offsets: a 2 GiB result is refused before any launch
+    (the operands here are small; the result tensor is really allocated, so a launch that slipped through would stay
+    inside it)."""
+    from vegans import _hip
+    from vegans.engine import ops
+    lib = _hip.load()
+    geo = ops.Geom(4, 256, 256, 8, 4096, 1, 1, 1, 1, 0, 0)           # 2^18 pixels x 4096 channels x 2 bytes = 2 GiB
+    assert lib.vg_conv2d_h_applies(0, ctypes.byref(geo.c))
+    x = torch.zeros(4 * 256 * 256 * 8, dtype=torch.bfloat16, device=gpu)
+    w = torch.zeros(4096 * 8, dtype=torch.bfloat16, device=gpu)
+    y = torch.empty(1 << 30, dtype=torch.bfloat16, device=gpu)
+    P = lambda t: ctypes.c_void_p(t.data_ptr())
+    assert lib.vg_conv2d_fwd_h(ctypes.byref(geo.c), P(x), P(w), None, P(y), None) == -1
+    assert b"2 GiB" in lib.vg_last_error()
+
+
 @pytest.mark.parametrize("shape,act", [((6, 64, 9, 7), 2), ((33, 128), 1), ((4, 24, 5, 5), 0), ((3, 7, 4, 4), 2)])
 def test_norm_and_activation_h_kernels_equal_their_f32_twins(gpu, shape, act):
     """BatchNorm (statistics, apply, backward, double backward) and activation kernels on bf16 storage: all arithmetic is
