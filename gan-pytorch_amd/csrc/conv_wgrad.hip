@@ -190,6 +190,72 @@ extern "C" int vg_conv2d_wgrad_reduce_h(const vg_conv_geom* g, float* gw, const 
   return VG_OK;
 }
 
+// Several (gy, x) pairs of one geometry in one launch: the weight gradient of a layer that several passes of a
+// training step ran through is the sum over the passes, and one launch over all of them has the slab traffic and the
+// slab sum of a single pass (its splits are dealt out over the pairs). Up to four pairs.
+constexpr int kMaxPairsH = 4;
+static WgradPlan wgrad_plan_h_multi(const vg_conv_geom* g, int pairs) {
+  return pairs <= 1 ? wgrad_plan_h(g) : wgrad_plan(g, (kTargetBlocksH + pairs - 1) / pairs, 64);
+}
+
+extern "C" size_t vg_conv2d_wgrad_h_multi_workspace_bytes(const vg_conv_geom* g, int pairs) {
+  if (vg_check_geom(g, "vg_conv2d_wgrad_h_multi_workspace_bytes") || pairs < 1 || pairs > kMaxPairsH) return 0;
+  const WgradPlan pl = wgrad_plan_h_multi(g, pairs);
+  if (pl.nsplit * pairs <= 1) return 0;
+  return (size_t)pl.nsplit * pairs * pl.M * pl.Ncols * sizeof(float);
+}
+
+extern "C" int vg_conv2d_wgrad_reduce_h_multi(const vg_conv_geom* g, int pairs, float* gw, const void* workspace, void* stream) {
+  if (int e = vg_check_geom(g, "vg_conv2d_wgrad_reduce_h_multi")) return e;
+  VG_REQUIRE(pairs >= 1 && pairs <= kMaxPairsH, "vg_conv2d_wgrad_reduce_h_multi: one to four pairs");
+  const WgradPlan pl = wgrad_plan_h_multi(g, pairs);
+  if (pl.nsplit * pairs <= 1) return VG_OK;
+  VG_REQUIRE(gw && workspace, "vg_conv2d_wgrad_reduce_h_multi: null pointer");
+  launch_slab_reduce((const float*)workspace, gw, (size_t)pl.M * pl.Ncols, pl.nsplit * pairs, (hipStream_t)stream);
+  VG_CHECK_LAUNCH("vg_conv2d_wgrad_h_multi(slab reduce)");
+  return VG_OK;
+}
+
+extern "C" int vg_conv2d_wgrad_partial_h_multi(const vg_conv_geom* g, int pairs, const void* const* gy, const void* const* x,
+                                               float* gw, void* workspace, size_t workspace_bytes, void* stream) {
+  if (int e = vg_check_geom(g, "vg_conv2d_wgrad_partial_h_multi")) return e;
+  if (!vg_conv2d_h_applies(2, g))
+    return vg_fail(VG_ERR_INVALID, "vg_conv2d_wgrad_partial_h_multi: this geometry is not served on bf16 tensors (vg_conv2d_h_applies)");
+  VG_REQUIRE(pairs >= 1 && pairs <= kMaxPairsH && gy && x && gw, "vg_conv2d_wgrad_partial_h_multi: one to four pairs, no null pointers");
+  for (int i = 0; i < pairs; ++i)
+    VG_REQUIRE(gy[i] && x[i] && vg_aligned16(gy[i]) && vg_aligned16(x[i]), "vg_conv2d_wgrad_partial_h_multi: null or misaligned tensor");
+  const WgradPlan pl = wgrad_plan_h_multi(g, pairs);
+  const int nsplit = pl.nsplit * pairs;
+  const size_t need = nsplit > 1 ? (size_t)nsplit * pl.M * pl.Ncols * sizeof(float) : 0;
+  if (need > 0 && (!workspace || workspace_bytes < need || !vg_aligned16(workspace)))
+    return vg_fail(VG_ERR_WORKSPACE, "vg_conv2d_wgrad_partial_h_multi: workspace of %zu bytes (16-byte aligned) required, got %zu",
+                   need, workspace_bytes);
+  IgemmParams p{};
+  p.out = nsplit > 1 ? (float*)workspace : gw;
+  p.N = g->N; p.H = g->H; p.W = g->W; p.Ci = g->Ci; p.Co = g->Co; p.KH = g->kh; p.KW = g->kw;
+  p.Ho = g->Ho; p.Wo = g->Wo; p.sh = g->sh; p.sw = g->sw; p.ph = g->ph; p.pw = g->pw;
+  p.M = pl.M; p.Ncols = pl.Ncols; p.Ktot = pl.Ktot;
+  p.mtiles = pl.mtiles; p.ntiles = pl.ntiles;
+  p.kchunk = pl.kchunk;
+  p.bias_mod = 1;
+  p.slab_stride = nsplit > 1 ? (long long)pl.M * pl.Ncols : 0;
+  PgemmParams pp{};
+  pp.g = p;
+  if (int e = pgemm_prepare(pp, nullptr, (long long)g->N * g->Ho * g->Wo * g->Co, nullptr, (long long)g->N * g->H * g->W * g->Ci, 1,
+                            nullptr, 0, (hipStream_t)stream, "vg_conv2d_wgrad_partial_h_multi", gy[0], x[0]))
+    return e;
+  for (int i = 0; i < pairs; ++i) {
+    pp.Aseg[i] = (const __bf16*)gy[i];
+    pp.Bseg[i] = (const __bf16*)x[i];
+  }
+  pp.seg_splits = pl.nsplit;
+  dim3 grid((unsigned)(pl.mtiles * pl.ntiles), 1, (unsigned)nsplit);
+  if (pgemm_launch<MODE_WGRAD, 1>(pp, pl.bm, pl.bn, grid, (hipStream_t)stream) != 0)
+    return vg_fail(VG_ERR_INVALID, "vg_conv2d_wgrad_partial_h_multi: no plane kernel for tile %dx%d", pl.bm, pl.bn);
+  VG_CHECK_LAUNCH("vg_conv2d_wgrad_partial_h_multi");
+  return VG_OK;
+}
+
 static int wgrad_partial_impl(const vg_conv_geom* g, const float* gy, const float* x, float* gw, void* workspace,
                               size_t workspace_bytes, int precision, const void* gy_planes, const void* x_planes,
                               void* stream, bool io_h) {

@@ -34,6 +34,12 @@ struct PgemmParams {
   int mask_act;
   float mask_slope;
   unsigned out_bytes;            // bf16 results: size of the result tensor in bytes (below 2 GiB: pgemm_set_out_h)
+  // Weight gradient over several (gy, x) pairs of one geometry in one launch (the passes of a training step that share
+  // a layer): split z belongs to pair z / seg_splits and is split z % seg_splits of it; every split writes its own
+  // slab as before, so the slab sum is the sum over all pairs. seg_splits == 0: one pair, Ap / Bp.
+  const __bf16* Aseg[4];
+  const __bf16* Bseg[4];
+  int seg_splits;
 };
 
 static __device__ __attribute__((aligned(16))) unsigned int vg_zero_page_u[4] = {0u, 0u, 0u, 0u};  // never written
@@ -119,6 +125,7 @@ __global__ void __launch_bounds__(NW * 64, (NP == 1 && NW == 8 && MODE != MODE_W
   int M = p.M, Ktot = p.Ktot;
   int kbeg = 0, kend = p.Ktot;
   int cls_h = 0, cls_w = 0, off_h = 0, off_w = 0, Hc = 0, Wc = 0, nth = 0, ntw = 0, base_h = 0, base_w = 0;
+  const __bf16 *opA = pp.Ap, *opB = pp.Bp;       // plane 0 of this block's operands
   float tab_inv_roww = 0.f, tab_inv_plane = 0.f, tab_inv_ntw = 0.f;
   const bool tab = MODE == MODE_DGRAD && zz < p.ncls;     // the class's geometry as the host worked it out
   if constexpr (MODE == MODE_DGRAD) {
@@ -144,7 +151,14 @@ __global__ void __launch_bounds__(NW * 64, (NP == 1 && NW == 8 && MODE != MODE_W
     kend = Ktot;
     if (m0 >= M) return;  // block-uniform
   } else if constexpr (MODE == MODE_WGRAD) {
-    kbeg = zz * p.kchunk;
+    int zl = zz;
+    if (pp.seg_splits > 0) {
+      const int seg = zz / pp.seg_splits;
+      zl = zz - seg * pp.seg_splits;
+      opA = pp.Aseg[seg];
+      opB = pp.Bseg[seg];
+    }
+    kbeg = zl * p.kchunk;
     kend = min(kbeg + p.kchunk, p.Ktot);
   } else {
     ntw = p.KW;
@@ -317,8 +331,8 @@ __global__ void __launch_bounds__(NW * 64, (NP == 1 && NW == 8 && MODE != MODE_W
   // byte offset: a unit that must not be read gets an offset beyond the buffer and comes back as zeros (no 64-bit
   // address arithmetic and no pointer select in the k-walk; with bf16 MFMAs a k-step's address arithmetic on the vector
   // ALU takes as long as its matrix work).
-  const __amdgpu_buffer_rsrc_t rsrcA = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(pp.Ap), 0, (int)pp.a_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rsrcB = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(pp.Bp), 0, (int)pp.b_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrcA = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(opA), 0, (int)pp.a_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrcB = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(opB), 0, (int)pp.b_bytes, 0x00020000);
   const unsigned a_pbytes = (unsigned)pp.a_plane * 2u, b_pbytes = (unsigned)pp.b_plane * 2u;
   auto ld_planes = [&](const __amdgpu_buffer_rsrc_t& rs, unsigned pbytes, unsigned off, bool ok, u32x4 (&dst)[NP]) {
 #pragma unroll

@@ -132,6 +132,9 @@ SIGNATURES = {
     "vg_conv2d_wgrad_h_workspace_bytes": (c_size_t, [_G]),
     "vg_conv2d_wgrad_partial_h": (c_int, [_G, _P, _P, _P, _P, c_size_t, _P]),
     "vg_conv2d_wgrad_reduce_h": (c_int, [_G, _P, _P, _P]),
+    "vg_conv2d_wgrad_h_multi_workspace_bytes": (c_size_t, [_G, c_int]),
+    "vg_conv2d_wgrad_partial_h_multi": (c_int, [_G, c_int, _P, _P, _P, _P, c_size_t, _P]),
+    "vg_conv2d_wgrad_reduce_h_multi": (c_int, [_G, c_int, _P, _P, _P]),
     "vg_conv2d_stem_h_applies": (c_int, [c_int, _G]),
     "vg_conv2d_stem_fwd_h": (c_int, [_G, _P, _P, _P, _P, c_int, c_float, _P]),
     "vg_conv2d_stem_dgrad_h": (c_int, [_G, _P, _P, _P, _P, _P]),

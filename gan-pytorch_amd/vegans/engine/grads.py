@@ -58,6 +58,11 @@ def _wait_event(ev):
     torch.cuda.current_stream().wait_event(ev)
 
 
+def accepts(param):
+    """Whether a ledger is collecting for `param` (an operator may then leave it work instead of a tensor)."""
+    return _active is not None and id(param) in _active.index
+
+
 def route(param, label, grad):
     """Give `grad` (a contribution to d loss / d param, or None) to the collecting ledger and return None, or return it
     unchanged when no ledger is collecting for `param` (plain autograd use of the operators: autograd then
@@ -174,6 +179,26 @@ class Ledger:
         if self.sink is not None:
             self.sink.deposited(self, param, len(self.entries[key]))
 
+    def materialize(self, param):
+        """Run the contractions the operators left behind for `param` (ops.PendingWgrad): the pending pairs of one
+        geometry in label order, up to ops.MAX_WGRAD_PAIRS per launch; each launch's result takes the place of its
+        first pair."""
+        rows = self.entries.get(id(param))
+        if not rows or not any(getattr(t, "pending", False) for _, t in rows):
+            return
+        from . import ops
+        rows = sorted(rows, key=lambda r: r[0])
+        done = [r for r in rows if not getattr(r[1], "pending", False)]
+        groups = {}
+        for lab, t in rows:
+            if getattr(t, "pending", False):
+                groups.setdefault(t.key, []).append((lab, t))
+        for members in groups.values():
+            for i in range(0, len(members), ops.MAX_WGRAD_PAIRS):
+                part = members[i:i + ops.MAX_WGRAD_PAIRS]
+                done.append((part[0][0], ops.wgrad_of_pairs([t for _, t in part])))
+        self.entries[id(param)] = done
+
     def sources(self, param):
         rows = sorted(self.entries.get(id(param), ()), key=lambda r: r[0])
         return [t for _, t in rows]
@@ -188,6 +213,8 @@ class Ledger:
             for ev in self.events.pop(id(p), ()):
                 _wait_event(ev)
                 waited = True
+        for p in todo:
+            self.materialize(p)
         if self.sink is None:
             outs, scale = [None] * len(todo), 1.0
         else:

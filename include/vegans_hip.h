@@ -396,6 +396,16 @@ size_t vg_conv2d_wgrad_h_workspace_bytes(const vg_conv_geom* g);
 int vg_conv2d_wgrad_partial_h(const vg_conv_geom* g, const void* gy, const void* x, float* gw, void* workspace,
                               size_t workspace_bytes, void* stream);
 int vg_conv2d_wgrad_reduce_h(const vg_conv_geom* g, float* gw, const void* workspace, void* stream);
+/* The weight gradient of one layer summed over `pairs` (1..4) pairs (gy[i], x[i]) of one geometry, in one launch: what
+ * the reference's optimizer sees in weight.grad after the passes of a training step that ran through the layer have
+ * all back-propagated (WassersteinGANGP.py:88-107: the critic sees the fake batch, the real batch and the interpolates,
+ * and torch's AccumulateGrad adds the contributions one by one). gy and x are host arrays of device pointers; the
+ * slabs of all pairs lie in one workspace (vg_conv2d_wgrad_h_multi_workspace_bytes) and vg_conv2d_wgrad_reduce_h_multi
+ * adds them in pair order, split order within a pair. */
+size_t vg_conv2d_wgrad_h_multi_workspace_bytes(const vg_conv_geom* g, int pairs);
+int vg_conv2d_wgrad_partial_h_multi(const vg_conv_geom* g, int pairs, const void* const* gy, const void* const* x, float* gw,
+                                    void* workspace, size_t workspace_bytes, void* stream);
+int vg_conv2d_wgrad_reduce_h_multi(const vg_conv_geom* g, int pairs, float* gw, const void* workspace, void* stream);
 /* The layers next to an image in such a network (reference: the first nn.Conv2d of a critic and the last
  * nn.ConvTranspose2d of a generator, e.g. examples/example_input_formats.py:64-77) have an f32 image on one side and a
  * bf16 feature map on the other: forward f32 x -> bf16 y with an optional ReLU / LeakyReLU, input gradient bf16 gy ->

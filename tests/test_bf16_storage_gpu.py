@@ -118,6 +118,40 @@ def test_h_contractions_against_f32_on_the_same_bf16_values(gpu, case):
         assert _scale_err(gw, wr.grad) <= 2e-5, "weight gradient (f32 result of exact bf16 products)"
 
 
+@pytest.mark.parametrize("case,pairs", [((2, 64, 16, 16, 128, 4, 2, 1), 4), ((3, 16, 9, 7, 64, 3, 1, 1), 3),
+                                        ((4, 8, 24, 32, 64, 3, 2, 1), 2), ((5, 40, 6, 6, 72, 3, 2, 0), 1)])
+def test_h_weight_gradient_over_several_pairs_in_one_launch(gpu, case, pairs):
+    """vg_conv2d_wgrad_partial_h_multi + vg_conv2d_wgrad_reduce_h_multi: the weight gradient of one layer summed over
+    several (gy, x) pairs, against the sum of torch's f32 weight gradients of the same bf16 values on the CPU."""
+    from vegans import _hip
+    from vegans.engine import ops
+    N, Ci, H, W, Co, k, s, p = case
+    lib = _hip.load()
+    gen = torch.Generator().manual_seed(sum(case) + pairs)
+    geo = ops.Geom(N, H, W, Ci, Co, k, k, s, s, p, p)
+    assert lib.vg_conv2d_h_applies(2, ctypes.byref(geo.c))
+    CL = torch.channels_last
+    want = torch.zeros(Co, Ci, k, k)
+    xs, gs = [], []
+    for _ in range(pairs):
+        x = torch.randn(N, Ci, H, W, generator=gen).bfloat16()
+        gy = torch.randn(N, Co, geo.Ho, geo.Wo, generator=gen).bfloat16()
+        want += torch.nn.grad.conv2d_weight(x.float(), (Co, Ci, k, k), gy.float(), stride=s, padding=p)
+        xs.append(x.to(gpu).contiguous(memory_format=CL))
+        gs.append(gy.to(gpu).contiguous(memory_format=CL))
+    gw = torch.empty((Co, Ci, k, k), dtype=torch.float32, device=gpu, memory_format=CL)
+    nbytes = lib.vg_conv2d_wgrad_h_multi_workspace_bytes(ctypes.byref(geo.c), pairs)
+    ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=gpu)
+    P = lambda t: ctypes.c_void_p(t.data_ptr())
+    gptr = (ctypes.c_void_p * pairs)(*[t.data_ptr() for t in gs])
+    xptr = (ctypes.c_void_p * pairs)(*[t.data_ptr() for t in xs])
+    st = _hip._stream()
+    _hip.call("vg_conv2d_wgrad_partial_h_multi", ctypes.byref(geo.c), pairs, gptr, xptr, P(gw), P(ws), ctypes.c_size_t(nbytes), st)
+    _hip.call("vg_conv2d_wgrad_reduce_h_multi", ctypes.byref(geo.c), pairs, P(gw), P(ws), st)
+    assert _scale_err(gw, want) <= 2e-5
+    assert lib.vg_conv2d_wgrad_partial_h_multi(ctypes.byref(geo.c), 5, gptr, xptr, P(gw), P(ws), ctypes.c_size_t(nbytes), st) == -1
+
+
 def test_h_entry_points_refuse_shapes_they_do_not_serve(gpu):
     from vegans import _hip
     from vegans.engine import ops

@@ -254,6 +254,51 @@ def test_ledger_sums_in_label_order_on_cpu():
     assert a < b and a + (0,) < b
 
 
+def test_ledger_runs_pending_weight_gradients_grouped_by_geometry(monkeypatch):
+    """Contractions the operators leave with the ledger (ops.PendingWgrad): at the sum they run grouped by geometry, in
+    label order, at most ops.MAX_WGRAD_PAIRS per launch, and each launch's result stands where its first pair stood."""
+    from vegans.engine import grads, ops
+
+    class Pending:
+        pending = True
+        is_cuda = False
+
+        def __init__(self, key, value):
+            self.key, self.value = key, value
+
+        def detach(self):
+            return self
+
+    launches = []
+
+    def wgrad_of_pairs(items):
+        launches.append([(t.key, t.value) for t in items])
+        return torch.full((2,), float(sum(t.value for t in items)))
+
+    monkeypatch.setattr(ops, "wgrad_of_pairs", wgrad_of_pairs)
+    seen = []
+
+    def summer(items, scale):
+        out = []
+        for par, sources, dst in items:
+            seen.append([float(t[0]) for t in sources])
+            out.append(sum(sources[1:], sources[0].clone()) * scale)
+        return out
+
+    p = torch.nn.Parameter(torch.zeros(2))
+    with grads.Ledger([p], summer=summer):
+        assert grads.accepts(p)
+        for lab, key, v in (((7,), "a", 1.0), ((3,), "a", 2.0), ((5,), "b", 4.0), ((9,), "a", 8.0), ((1,), "a", 16.0),
+                            ((8,), "a", 32.0), ((2,), "a", 64.0)):
+            assert grads.route(p, lab, Pending(key, v)) is None
+        assert grads.route(p, (4,), torch.full((2,), 0.5)) is None
+    # geometry "a" in label order 1, 2, 3, 7 | 8, 9; geometry "b" alone; results stand at labels 1, 8 and 5
+    assert launches == [[("a", 16.0), ("a", 64.0), ("a", 2.0), ("a", 1.0)], [("a", 32.0), ("a", 8.0)], [("b", 4.0)]]
+    assert seen == [[83.0, 0.5, 4.0, 40.0]]
+    assert torch.equal(p.grad, torch.full((2,), 127.5))
+    assert not grads.accepts(p)
+
+
 def test_ledger_orders_sums_and_collectives_across_streams(monkeypatch):
     """Parameters that complete on alternating streams (the critic's fake / real / penalty chains run their backward
     nodes on three streams): the sum of a parameter must wait for the contributions of THAT parameter from every stream

@@ -64,5 +64,40 @@ def main():
                  t_app, 4 * mb / t_app * 1e3, t_app2, 3 * mb / t_app2 * 1e3))
 
 
+def main_h():
+    """The same on bf16 activations (the bf16 data path): statistics, backward reduce and apply with the mask from x."""
+    dev = torch.device("cuda")
+    for m, c in SHAPES[1:]:
+        x = torch.randn(m, c, device=dev).bfloat16()
+        gy = torch.randn(m, c, device=dev).bfloat16()
+        mean = torch.zeros(c, device=dev)
+        invstd = torch.ones(c, device=dev)
+        gamma = torch.ones(c, device=dev)
+        beta = torch.zeros(c, device=dev)
+        sums = torch.empty(2, c, device=dev)
+        gx = torch.empty_like(x)
+        y = torch.empty_like(x)
+        nbytes = _hip.load().vg_bn_workspace_bytes(m, c)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        wsp = ctypes.c_void_p(ws.data_ptr())
+        P = lambda t: ctypes.c_void_p(t.data_ptr())
+        t_stats = timed(lambda: call("vg_bn_stats_h", P(x), m, c, c_float(1e-5), c_float(0.1), _ptr(mean), _ptr(invstd),
+                                     None, None, None, wsp, c_size_t(nbytes), _stream()), 200)
+        t_fwd = timed(lambda: call("vg_bn_apply_h", P(x), _ptr(mean), _ptr(invstd), _ptr(gamma), _ptr(beta), P(y), m, c,
+                                   _hip.ACT_LRELU, c_float(0.2), _stream()), 200)
+        t_red = timed(lambda: call("vg_bn_bwd_reduce_h", P(gy), P(x), _ptr(mean), _ptr(invstd), m, c, _ptr(sums), wsp,
+                                   c_size_t(nbytes), None, _hip.ACT_LRELU, c_float(0.2), _ptr(gamma), _ptr(beta), _stream()), 200)
+        t_app = timed(lambda: call("vg_bn_bwd_apply_h", P(gy), P(x), _ptr(mean), _ptr(invstd), _ptr(gamma), _ptr(sums),
+                                   P(gx), m, c, None, _hip.ACT_LRELU, c_float(0.2), _ptr(beta), _stream()), 200)
+        mb = m * c * 2 / 1e6
+        print("bf16 M=%7d C=%3d (%5.1f MB/tensor)  stats+final %5.1f us %5.0f GB/s | apply %5.1f us %5.0f GB/s | bwd reduce+final "
+              "%5.1f us %5.0f GB/s | bwd apply %5.1f us %5.0f GB/s"
+              % (m, c, mb, t_stats, mb / t_stats * 1e3, t_fwd, 2 * mb / t_fwd * 1e3, t_red, 2 * mb / t_red * 1e3,
+                 t_app, 3 * mb / t_app * 1e3))
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "bf16":
+        main_h()
+    else:
+        main()
