@@ -407,6 +407,14 @@ class _PlaneCache:
     def clear(self):
         self.entries.clear()
 
+    def drop(self, tensors):
+        """Forget what was made of `tensors` (parameters an optimizer is about to rewrite in place, behind torch's version
+        counters); the other network's weights keep their copies for the rest of the iteration."""
+        for t in tensors:
+            ptr = t.data_ptr()
+            self.entries.pop(ptr, None)
+            self.entries.pop((ptr, "h"), None)
+
     def pointer(self, mode, g, t):
         """Device pointer to the planes of `t` (already in kernel memory order), or None when the library should split
         the operand itself."""

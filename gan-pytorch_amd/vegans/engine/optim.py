@@ -50,7 +50,8 @@ def _grad_mem(p):
 def fused_step(optimizer, grad_scale=1.0, clamp=None):
     """One optimizer step for every parameter that has a gradient. `clamp=(lo, hi)` clamps after the update."""
     from . import ops
-    ops.plane_cache.clear()      # the kernels below rewrite parameters in place, behind torch's version counters
+    # the kernels below rewrite parameters in place, behind torch's version counters
+    ops.plane_cache.drop([p for group in optimizer.param_groups for p in group["params"]])
     lo, hi = clamp if clamp is not None else _NO_CLAMP
     kind = type(optimizer)
     if kind is torch.optim.RMSprop:
@@ -187,5 +188,8 @@ def _sgd(opt, grad_scale, lo, hi):
 
 
 def clamp_(params, lo, hi):
+    from . import ops
+    params = list(params)
+    ops.plane_cache.drop(params)
     for p in params:
         call("vg_clamp", _ptr(p.data), c_size_t(p.numel()), c_float(lo), c_float(hi), _stream())
