@@ -208,6 +208,24 @@ __device__ __forceinline__ float act_grad(float ref, int act, float slope) {
   }
 }
 
+// The slope mask of a ReLU / LeakyReLU (the only activations fused behind a norm: check_mask_act) without the switch:
+// inside a per-element loop the switch is a chain of scalar branches per element.
+__device__ __forceinline__ float mask_low(int act, float slope) { return act == VG_ACT_RELU ? 0.f : slope; }
+__device__ __forceinline__ float mask_of(float ref, float low) { return ref > 0.f ? 1.f : low; }
+
+// The channel group of element group i of an [M][C] tensor walked with a grid stride, without a division per step.
+// When the stride is a multiple of the groups per row (every power-of-two channel count), a thread stays on one
+// channel group and loads its per-channel values once: on bf16 tensors the four to seven 16-byte parameter loads per
+// 8 bytes of data, not HBM, bounded these kernels.
+struct ChannelWalk {
+  int cg, step, CG;
+  __device__ ChannelWalk(size_t i0, size_t stride, int CG_) : cg((int)(i0 % (size_t)CG_)), step((int)(stride % (size_t)CG_)), CG(CG_) {}
+  __device__ bool fixed() const { return step == 0; }
+  __device__ void next() {
+    cg += step;
+    if (cg >= CG) cg -= CG;
+  }
+};
 
 // ---- functors -------------------------------------------------------------------------------------
 template <class T>
@@ -258,14 +276,16 @@ struct BnBwdF {  // sum g, sum g*xhat with g = gy * act'(.) when an activation i
     if (act_out) {
       float y[VEC];
       ldv<VEC>(act_out + off, y);
+      const float low = mask_low(act, slope);
 #pragma unroll
-      for (int e = 0; e < VEC; ++e) g[e] *= act_grad(y[e], act, slope);
+      for (int e = 0; e < VEC; ++e) g[e] *= mask_of(y[e], low);
     } else if (act != VG_ACT_NONE) {
       float ga[VEC], be[VEC];
       if (gamma) ldv<VEC>(gamma + c, ga);
       if (beta) ldv<VEC>(beta + c, be);
+      const float low = mask_low(act, slope);
 #pragma unroll
-      for (int e = 0; e < VEC; ++e) g[e] *= act_grad(vg_bn_affine(a[e], mu[e], r[e], gamma, ga[e], beta, be[e]), act, slope);
+      for (int e = 0; e < VEC; ++e) g[e] *= mask_of(vg_bn_affine(a[e], mu[e], r[e], gamma, ga[e], beta, be[e]), low);
     }
 #pragma unroll
     for (int e = 0; e < VEC; ++e) {
@@ -295,14 +315,16 @@ struct BnDbwdF {  // sum g, sum g*xhat, sum u, sum u*xhat, sum u*g   (g as in Bn
     if (act_out) {
       float y[VEC];
       ldv<VEC>(act_out + off, y);
+      const float low = mask_low(act, slope);
 #pragma unroll
-      for (int e = 0; e < VEC; ++e) g[e] *= act_grad(y[e], act, slope);
+      for (int e = 0; e < VEC; ++e) g[e] *= mask_of(y[e], low);
     } else if (act != VG_ACT_NONE) {
       float ga[VEC], be[VEC];
       if (gamma) ldv<VEC>(gamma + c, ga);
       if (beta) ldv<VEC>(beta + c, be);
+      const float low = mask_low(act, slope);
 #pragma unroll
-      for (int e = 0; e < VEC; ++e) g[e] *= act_grad(vg_bn_affine(a[e], mu[e], r[e], gamma, ga[e], beta, be[e]), act, slope);
+      for (int e = 0; e < VEC; ++e) g[e] *= mask_of(vg_bn_affine(a[e], mu[e], r[e], gamma, ga[e], beta, be[e]), low);
     }
 #pragma unroll
     for (int e = 0; e < VEC; ++e) {
@@ -478,19 +500,38 @@ __global__ void __launch_bounds__(256) bn_apply_kernel(const T* __restrict__ x, 
                                                        const float* __restrict__ invstd, const float* __restrict__ gamma,
                                                        const float* __restrict__ beta, T* __restrict__ y, size_t nvec,
                                                        int C, int act, float slope) {
-  const int CG = C / VEC;
   const size_t stride = (size_t)gridDim.x * blockDim.x;
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += stride) {
-    const int c = (int)(i % CG) * VEC;
-    float a[VEC], mu[VEC], r[VEC], ga[VEC], be[VEC], o[VEC];
-    ldv<VEC>(x + i * VEC, a);
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nvec) return;
+  ChannelWalk cw(i, stride, C / VEC);
+  float mu[VEC], r[VEC], ga[VEC], be[VEC];
+  auto load_channel = [&]() {
+    const int c = cw.cg * VEC;
     ldv<VEC>(mean + c, mu);
     ldv<VEC>(invstd + c, r);
     if (gamma) ldv<VEC>(gamma + c, ga);
     if (beta) ldv<VEC>(beta + c, be);
+  };
+  load_channel();
+  const bool simple = act == VG_ACT_NONE || act == VG_ACT_RELU || act == VG_ACT_LRELU;
+  const bool none = act == VG_ACT_NONE, relu = act == VG_ACT_RELU;
+  for (; i < nvec; i += stride) {
+    if (!cw.fixed()) load_channel();
+    float a[VEC], o[VEC];
+    ldv<VEC>(x + i * VEC, a);
+    if (simple) {         // no switch per element
 #pragma unroll
-    for (int e = 0; e < VEC; ++e) o[e] = act_apply(vg_bn_affine(a[e], mu[e], r[e], gamma, ga[e], beta, be[e]), act, slope);
+      for (int e = 0; e < VEC; ++e) {
+        const float v = vg_bn_affine(a[e], mu[e], r[e], gamma, ga[e], beta, be[e]);
+        const float neg = relu ? 0.f : v * slope;
+        o[e] = (none || v > 0.f) ? v : neg;
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) o[e] = act_apply(vg_bn_affine(a[e], mu[e], r[e], gamma, ga[e], beta, be[e]), act, slope);
+    }
     stv<VEC>(y + i * VEC, o);
+    if (!cw.fixed()) cw.next();
   }
 }
 
@@ -501,29 +542,37 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const T* __restrict__
                                                            T* __restrict__ gx, size_t nvec, int C, float inv_n,
                                                            const T* __restrict__ act_out, int act, float slope,
                                                            const float* __restrict__ beta) {
-  const int CG = C / VEC;
   const size_t stride = (size_t)gridDim.x * blockDim.x;
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += stride) {
-    const int c = (int)(i % CG) * VEC;
-    float g[VEC], a[VEC], mu[VEC], r[VEC], ga[VEC], sg[VEC], sgx[VEC], o[VEC];
-    ldv<VEC>(gy + i * VEC, g);
-    ldv<VEC>(x + i * VEC, a);
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nvec) return;
+  ChannelWalk cw(i, stride, C / VEC);
+  float mu[VEC], r[VEC], ga[VEC], be[VEC], sg[VEC], sgx[VEC];
+  const bool from_x = !act_out && act != VG_ACT_NONE;      // the mask is rebuilt from the norm's input
+  auto load_channel = [&]() {
+    const int c = cw.cg * VEC;
     ldv<VEC>(mean + c, mu);
     ldv<VEC>(invstd + c, r);
     if (gamma) ldv<VEC>(gamma + c, ga);
+    if (from_x && beta) ldv<VEC>(beta + c, be);
+    ldv<VEC>(sums + c, sg);
+    ldv<VEC>(sums + C + c, sgx);
+  };
+  load_channel();
+  const float low = mask_low(act, slope);
+  for (; i < nvec; i += stride) {
+    if (!cw.fixed()) load_channel();
+    float g[VEC], a[VEC], o[VEC];
+    ldv<VEC>(gy + i * VEC, g);
+    ldv<VEC>(x + i * VEC, a);
     if (act_out) {
       float y[VEC];
       ldv<VEC>(act_out + i * VEC, y);
 #pragma unroll
-      for (int e = 0; e < VEC; ++e) g[e] *= act_grad(y[e], act, slope);
-    } else if (act != VG_ACT_NONE) {
-      float be[VEC];
-      if (beta) ldv<VEC>(beta + c, be);
+      for (int e = 0; e < VEC; ++e) g[e] *= mask_of(y[e], low);
+    } else if (from_x) {
 #pragma unroll
-      for (int e = 0; e < VEC; ++e) g[e] *= act_grad(vg_bn_affine(a[e], mu[e], r[e], gamma, ga[e], beta, be[e]), act, slope);
+      for (int e = 0; e < VEC; ++e) g[e] *= mask_of(vg_bn_affine(a[e], mu[e], r[e], gamma, ga[e], beta, be[e]), low);
     }
-    ldv<VEC>(sums + c, sg);
-    ldv<VEC>(sums + C + c, sgx);
 #pragma unroll
     for (int e = 0; e < VEC; ++e) {
       const float xh = (a[e] - mu[e]) * r[e];
@@ -531,6 +580,7 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const T* __restrict__
       o[e] = sc * (g[e] - sg[e] * inv_n - xh * (sgx[e] * inv_n));
     }
     stv<VEC>(gx + i * VEC, o);
+    if (!cw.fixed()) cw.next();
   }
 }
 
@@ -538,17 +588,25 @@ template <int VEC, class T>
 __global__ void __launch_bounds__(256) bn_bwd_eval_kernel(const T* __restrict__ gy, const float* __restrict__ invstd,
                                                           const float* __restrict__ gamma, T* __restrict__ gx,
                                                           size_t nvec, int C) {
-  const int CG = C / VEC;
   const size_t stride = (size_t)gridDim.x * blockDim.x;
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += stride) {
-    const int c = (int)(i % CG) * VEC;
-    float g[VEC], r[VEC], ga[VEC], o[VEC];
-    ldv<VEC>(gy + i * VEC, g);
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nvec) return;
+  ChannelWalk cw(i, stride, C / VEC);
+  float r[VEC], ga[VEC];
+  auto load_channel = [&]() {
+    const int c = cw.cg * VEC;
     ldv<VEC>(invstd + c, r);
     if (gamma) ldv<VEC>(gamma + c, ga);
+  };
+  load_channel();
+  for (; i < nvec; i += stride) {
+    if (!cw.fixed()) load_channel();
+    float g[VEC], o[VEC];
+    ldv<VEC>(gy + i * VEC, g);
 #pragma unroll
     for (int e = 0; e < VEC; ++e) o[e] = g[e] * (gamma ? r[e] * ga[e] : r[e]);
     stv<VEC>(gx + i * VEC, o);
+    if (!cw.fixed()) cw.next();
   }
 }
 
@@ -560,33 +618,18 @@ __global__ void __launch_bounds__(256) bn_dbwd_apply_kernel(
     const float* __restrict__ gamma, const float* __restrict__ sums5, T* __restrict__ d_gy, T* __restrict__ d_x,
     size_t nvec, int C, float inv_n, const T* __restrict__ act_out, int act, float slope,
     const float* __restrict__ beta) {
-  const int CG = C / VEC;
   const size_t stride = (size_t)gridDim.x * blockDim.x;
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += stride) {
-    const int c = (int)(i % CG) * VEC;
-    float g[VEC], a[VEC], uu[VEC], mu[VEC], r[VEC], ga[VEC], vv[VEC], ww[VEC];
-    float s0[VEC], s1[VEC], s2[VEC], s3[VEC], s4[VEC], o1[VEC], o2[VEC], mk[VEC];
-    ldv<VEC>(gy + i * VEC, g);
-    ldv<VEC>(x + i * VEC, a);
-    ldv<VEC>(u + i * VEC, uu);
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nvec) return;
+  ChannelWalk cw(i, stride, C / VEC);
+  float mu[VEC], r[VEC], ga[VEC], be[VEC], vv[VEC], ww[VEC], s0[VEC], s1[VEC], s2[VEC], s3[VEC], s4[VEC];
+  const bool from_x = !act_out && act != VG_ACT_NONE;
+  auto load_channel = [&]() {
+    const int c = cw.cg * VEC;
     ldv<VEC>(mean + c, mu);
     ldv<VEC>(invstd + c, r);
     if (gamma) ldv<VEC>(gamma + c, ga);
-#pragma unroll
-    for (int e = 0; e < VEC; ++e) mk[e] = 1.f;
-    if (act_out) {
-      float y[VEC];
-      ldv<VEC>(act_out + i * VEC, y);
-#pragma unroll
-      for (int e = 0; e < VEC; ++e) mk[e] = act_grad(y[e], act, slope);
-    } else if (act != VG_ACT_NONE) {
-      float be[VEC];
-      if (beta) ldv<VEC>(beta + c, be);
-#pragma unroll
-      for (int e = 0; e < VEC; ++e) mk[e] = act_grad(vg_bn_affine(a[e], mu[e], r[e], gamma, ga[e], beta, be[e]), act, slope);
-    }
-#pragma unroll
-    for (int e = 0; e < VEC; ++e) g[e] *= mk[e];
+    if (from_x && beta) ldv<VEC>(beta + c, be);
     if (v) ldv<VEC>(v + c, vv);
     if (w) ldv<VEC>(w + c, ww);
     ldv<VEC>(sums5 + c, s0);
@@ -594,6 +637,28 @@ __global__ void __launch_bounds__(256) bn_dbwd_apply_kernel(
     ldv<VEC>(sums5 + 2 * C + c, s2);
     ldv<VEC>(sums5 + 3 * C + c, s3);
     ldv<VEC>(sums5 + 4 * C + c, s4);
+  };
+  load_channel();
+  const float low = mask_low(act, slope);
+  for (; i < nvec; i += stride) {
+    if (!cw.fixed()) load_channel();
+    float g[VEC], a[VEC], uu[VEC], o1[VEC], o2[VEC], mk[VEC];
+    ldv<VEC>(gy + i * VEC, g);
+    ldv<VEC>(x + i * VEC, a);
+    ldv<VEC>(u + i * VEC, uu);
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) mk[e] = 1.f;
+    if (act_out) {
+      float y[VEC];
+      ldv<VEC>(act_out + i * VEC, y);
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) mk[e] = mask_of(y[e], low);
+    } else if (from_x) {
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) mk[e] = mask_of(vg_bn_affine(a[e], mu[e], r[e], gamma, ga[e], beta, be[e]), low);
+    }
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) g[e] *= mk[e];
 #pragma unroll
     for (int e = 0; e < VEC; ++e) {
       const float xh = (a[e] - mu[e]) * r[e];
@@ -613,6 +678,7 @@ __global__ void __launch_bounds__(256) bn_dbwd_apply_kernel(
     }
     stv<VEC>(d_gy + i * VEC, o1);
     stv<VEC>(d_x + i * VEC, o2);
+    if (!cw.fixed()) cw.next();
   }
 }
 

@@ -1,8 +1,9 @@
 """Which kernels a multi-stream iteration is waiting for: from a `rocprofv3 --kernel-trace` output directory, the time
 during which exactly one kernel is running (and so nothing hides it), the time no kernel is running, and the time with
 two or more, each broken down by kernel name.
-    python tools/critical_path.py <rocprof output dir> [window ms]
-The window (default 40 ms) ends 2 ms before the last kernel: the replayed iterations at the end of a benchmark run.
+    python tools/critical_path.py <rocprof output dir> [window ms] [end offset ms]
+The window (default 40 ms) ends `end offset` (default 2 ms) before the last kernel: the replayed iterations at the end of
+a benchmark run made with --no-kernel-timing (with kernel timing the run ends in eager, instrumented iterations).
 """
 import collections
 import csv
@@ -17,7 +18,7 @@ def main():
     path = glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True)[0]
     rows = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]) for r in csv.DictReader(open(path))]
     rows.sort()
-    t_hi = max(r[1] for r in rows) - 2e6
+    t_hi = max(r[1] for r in rows) - (float(sys.argv[3]) if len(sys.argv) > 3 else 2.0) * 1e6
     t_lo = t_hi - window * 1e6
     rows = [r for r in rows if r[0] >= t_lo and r[1] <= t_hi]
     events = []
