@@ -49,8 +49,10 @@ __global__ void __launch_bounds__(256) colreduce_partial(F f, int M, int C, int 
 #pragma unroll
       for (int e = 0; e < VEC; ++e) acc[v][e] = 0.f;
     if (ty < TY && cg < cg_hi) {
+      typename F::template Ch<VEC> ch;
+      f.template channel<VEC>(cg * VEC, ch);
 #pragma unroll 4
-      for (int row = row0 + ty; row < row1; row += TY) f.template eval<VEC>((size_t)row * C + (size_t)cg * VEC, cg * VEC, acc);
+      for (int row = row0 + ty; row < row1; row += TY) f.template eval<VEC>((size_t)row * C + (size_t)cg * VEC, ch, acc);
     }
 #pragma unroll
     for (int v = 0; v < NV; ++v)
@@ -228,11 +230,19 @@ struct ChannelWalk {
 };
 
 // ---- functors -------------------------------------------------------------------------------------
+// A functor of the column reduction has a per-channel part, fetched once per thread before its rows (channel()), and a
+// per-row part (eval()). Everything eval() loads, it loads unconditionally: with the per-channel loads and the
+// activation-dependent branches inside the row loop, the compiler put a wait for ALL outstanding loads into every
+// row, so a thread's rows went to memory one after the other instead of four at a time.
 template <class T>
 struct SumF {  // colsum
   const T* x;
   template <int VEC>
-  __device__ void eval(size_t off, int c, float (&acc)[1][VEC]) const {
+  struct Ch {};
+  template <int VEC>
+  __device__ void channel(int c, Ch<VEC>& ch) const {}
+  template <int VEC>
+  __device__ void eval(size_t off, const Ch<VEC>& ch, float (&acc)[1][VEC]) const {
     float a[VEC];
     ldv<VEC>(x + off, a);
 #pragma unroll
@@ -244,22 +254,40 @@ template <class T>
 struct ShiftedMomentsF {  // sums of (x - x[0][c]) and its square
   const T* x;
   template <int VEC>
-  __device__ void eval(size_t off, int c, float (&acc)[2][VEC]) const {
-    float a[VEC], s[VEC];
+  struct Ch {
+    float s[VEC];
+  };
+  template <int VEC>
+  __device__ void channel(int c, Ch<VEC>& ch) const {
+    ldv<VEC>(x + c, ch.s);
+  }
+  template <int VEC>
+  __device__ void eval(size_t off, const Ch<VEC>& ch, float (&acc)[2][VEC]) const {
+    float a[VEC];
     ldv<VEC>(x + off, a);
-    ldv<VEC>(x + c, s);
 #pragma unroll
     for (int e = 0; e < VEC; ++e) {
-      const float d = a[e] - s[e];
+      const float d = a[e] - ch.s[e];
       acc[0][e] += d;
       acc[1][e] = fmaf(d, d, acc[1][e]);
     }
   }
 };
 
-template <class T>
-struct BnBwdF {  // sum g, sum g*xhat with g = gy * act'(.) when an activation is fused behind the norm: the mask comes
-                 // from the activation's output (act_out) or, without it, from the recomputed pre-activation
+// Where the slope mask of an activation fused behind the norm comes from: nowhere (no activation), the activation's
+// output, or the pre-activation recomputed from the norm's input (bit for bit what the forward pass saw).
+enum { MASK_NONE = 0, MASK_ACT_OUT = 1, MASK_FROM_X = 2 };
+static inline int mask_source(const void* act_out, int act) {
+  return act_out ? MASK_ACT_OUT : (act != VG_ACT_NONE ? MASK_FROM_X : MASK_NONE);
+}
+
+template <int VEC>
+struct BnChannel {
+  float mu[VEC], r[VEC], ga[VEC], be[VEC];
+};
+
+template <class T, int MASK>
+struct BnBwdF {  // sum g, sum g*xhat with g = gy * act'(.) when an activation is fused behind the norm
   const T *gy, *x;
   const float *mean, *invstd;
   const T* act_out;
@@ -267,36 +295,42 @@ struct BnBwdF {  // sum g, sum g*xhat with g = gy * act'(.) when an activation i
   int act;
   float slope;
   template <int VEC>
-  __device__ void eval(size_t off, int c, float (&acc)[2][VEC]) const {
-    float g[VEC], a[VEC], mu[VEC], r[VEC];
+  using Ch = BnChannel<VEC>;
+  template <int VEC>
+  __device__ void channel(int c, Ch<VEC>& ch) const {
+    ldv<VEC>(mean + c, ch.mu);
+    ldv<VEC>(invstd + c, ch.r);
+    if constexpr (MASK == MASK_FROM_X) {
+      if (gamma) ldv<VEC>(gamma + c, ch.ga);
+      if (beta) ldv<VEC>(beta + c, ch.be);
+    }
+  }
+  template <int VEC>
+  __device__ void eval(size_t off, const Ch<VEC>& ch, float (&acc)[2][VEC]) const {
+    float g[VEC], a[VEC];
     ldv<VEC>(gy + off, g);
     ldv<VEC>(x + off, a);
-    ldv<VEC>(mean + c, mu);
-    ldv<VEC>(invstd + c, r);
-    if (act_out) {
+    const float low = mask_low(act, slope);
+    if constexpr (MASK == MASK_ACT_OUT) {
       float y[VEC];
       ldv<VEC>(act_out + off, y);
-      const float low = mask_low(act, slope);
 #pragma unroll
       for (int e = 0; e < VEC; ++e) g[e] *= mask_of(y[e], low);
-    } else if (act != VG_ACT_NONE) {
-      float ga[VEC], be[VEC];
-      if (gamma) ldv<VEC>(gamma + c, ga);
-      if (beta) ldv<VEC>(beta + c, be);
-      const float low = mask_low(act, slope);
+    } else if constexpr (MASK == MASK_FROM_X) {
 #pragma unroll
-      for (int e = 0; e < VEC; ++e) g[e] *= mask_of(vg_bn_affine(a[e], mu[e], r[e], gamma, ga[e], beta, be[e]), low);
+      for (int e = 0; e < VEC; ++e)
+        g[e] *= mask_of(vg_bn_affine(a[e], ch.mu[e], ch.r[e], gamma, ch.ga[e], beta, ch.be[e]), low);
     }
 #pragma unroll
     for (int e = 0; e < VEC; ++e) {
-      const float xh = (a[e] - mu[e]) * r[e];
+      const float xh = (a[e] - ch.mu[e]) * ch.r[e];
       acc[0][e] += g[e];
       acc[1][e] = fmaf(g[e], xh, acc[1][e]);
     }
   }
 };
 
-template <class T>
+template <class T, int MASK>
 struct BnDbwdF {  // sum g, sum g*xhat, sum u, sum u*xhat, sum u*g   (g as in BnBwdF)
   const T *gy, *x, *u;
   const float *mean, *invstd;
@@ -305,30 +339,36 @@ struct BnDbwdF {  // sum g, sum g*xhat, sum u, sum u*xhat, sum u*g   (g as in Bn
   int act;
   float slope;
   template <int VEC>
-  __device__ void eval(size_t off, int c, float (&acc)[5][VEC]) const {
-    float g[VEC], a[VEC], uu[VEC], mu[VEC], r[VEC];
+  using Ch = BnChannel<VEC>;
+  template <int VEC>
+  __device__ void channel(int c, Ch<VEC>& ch) const {
+    ldv<VEC>(mean + c, ch.mu);
+    ldv<VEC>(invstd + c, ch.r);
+    if constexpr (MASK == MASK_FROM_X) {
+      if (gamma) ldv<VEC>(gamma + c, ch.ga);
+      if (beta) ldv<VEC>(beta + c, ch.be);
+    }
+  }
+  template <int VEC>
+  __device__ void eval(size_t off, const Ch<VEC>& ch, float (&acc)[5][VEC]) const {
+    float g[VEC], a[VEC], uu[VEC];
     ldv<VEC>(gy + off, g);
     ldv<VEC>(x + off, a);
     ldv<VEC>(u + off, uu);
-    ldv<VEC>(mean + c, mu);
-    ldv<VEC>(invstd + c, r);
-    if (act_out) {
+    const float low = mask_low(act, slope);
+    if constexpr (MASK == MASK_ACT_OUT) {
       float y[VEC];
       ldv<VEC>(act_out + off, y);
-      const float low = mask_low(act, slope);
 #pragma unroll
       for (int e = 0; e < VEC; ++e) g[e] *= mask_of(y[e], low);
-    } else if (act != VG_ACT_NONE) {
-      float ga[VEC], be[VEC];
-      if (gamma) ldv<VEC>(gamma + c, ga);
-      if (beta) ldv<VEC>(beta + c, be);
-      const float low = mask_low(act, slope);
+    } else if constexpr (MASK == MASK_FROM_X) {
 #pragma unroll
-      for (int e = 0; e < VEC; ++e) g[e] *= mask_of(vg_bn_affine(a[e], mu[e], r[e], gamma, ga[e], beta, be[e]), low);
+      for (int e = 0; e < VEC; ++e)
+        g[e] *= mask_of(vg_bn_affine(a[e], ch.mu[e], ch.r[e], gamma, ch.ga[e], beta, ch.be[e]), low);
     }
 #pragma unroll
     for (int e = 0; e < VEC; ++e) {
-      const float xh = (a[e] - mu[e]) * r[e];
+      const float xh = (a[e] - ch.mu[e]) * ch.r[e];
       acc[0][e] += g[e];
       acc[1][e] = fmaf(g[e], xh, acc[1][e]);
       acc[2][e] += uu[e];
@@ -827,9 +867,18 @@ int bn_bwd_reduce_impl(const char* who, const T* gy, const T* x, const float* me
                        const float* gamma, const float* beta, void* stream) {
   VG_REQUIRE(gy && x && mean && invstd && sums && M > 0 && C > 0, "%s: bad arguments", who);
   if (int e = check_mask_act(act_out, act, who)) return e;
-  BnBwdF<T> f{gy, x, mean, invstd, act_out, gamma, beta, act, slope};
-  return run_colreduce<2>(who, f, M, C, all_aligned({gy, x, mean, invstd, act_out, gamma, beta}), sums, ws, ws_bytes,
-                          (hipStream_t)stream);
+  const bool vec_ok = all_aligned({gy, x, mean, invstd, act_out, gamma, beta});
+  switch (mask_source(act_out, act)) {
+    case MASK_ACT_OUT:
+      return run_colreduce<2>(who, BnBwdF<T, MASK_ACT_OUT>{gy, x, mean, invstd, act_out, gamma, beta, act, slope}, M, C, vec_ok,
+                              sums, ws, ws_bytes, (hipStream_t)stream);
+    case MASK_FROM_X:
+      return run_colreduce<2>(who, BnBwdF<T, MASK_FROM_X>{gy, x, mean, invstd, act_out, gamma, beta, act, slope}, M, C, vec_ok,
+                              sums, ws, ws_bytes, (hipStream_t)stream);
+    default:
+      return run_colreduce<2>(who, BnBwdF<T, MASK_NONE>{gy, x, mean, invstd, act_out, gamma, beta, act, slope}, M, C, vec_ok,
+                              sums, ws, ws_bytes, (hipStream_t)stream);
+  }
 }
 
 template <class T>
@@ -864,9 +913,18 @@ int bn_dbwd_reduce_impl(const char* who, const T* gy, const T* x, const T* u, co
                         const float* gamma, const float* beta, void* stream) {
   VG_REQUIRE(gy && x && u && mean && invstd && sums5 && M > 0 && C > 0, "%s: bad arguments", who);
   if (int e = check_mask_act(act_out, act, who)) return e;
-  BnDbwdF<T> f{gy, x, u, mean, invstd, act_out, gamma, beta, act, slope};
-  return run_colreduce<5>(who, f, M, C, all_aligned({gy, x, u, mean, invstd, act_out, gamma, beta}), sums5, ws,
-                          ws_bytes, (hipStream_t)stream);
+  const bool vec_ok = all_aligned({gy, x, u, mean, invstd, act_out, gamma, beta});
+  switch (mask_source(act_out, act)) {
+    case MASK_ACT_OUT:
+      return run_colreduce<5>(who, BnDbwdF<T, MASK_ACT_OUT>{gy, x, u, mean, invstd, act_out, gamma, beta, act, slope}, M, C,
+                              vec_ok, sums5, ws, ws_bytes, (hipStream_t)stream);
+    case MASK_FROM_X:
+      return run_colreduce<5>(who, BnDbwdF<T, MASK_FROM_X>{gy, x, u, mean, invstd, act_out, gamma, beta, act, slope}, M, C,
+                              vec_ok, sums5, ws, ws_bytes, (hipStream_t)stream);
+    default:
+      return run_colreduce<5>(who, BnDbwdF<T, MASK_NONE>{gy, x, u, mean, invstd, act_out, gamma, beta, act, slope}, M, C,
+                              vec_ok, sums5, ws, ws_bytes, (hipStream_t)stream);
+  }
 }
 
 template <class T>
