@@ -85,19 +85,32 @@ struct StoreSumsE {   // plain result: out[v][c]
   }
 };
 
+// 8 channels x 32 block-lanes per workgroup. The partials were written by other compute units and come from memory: a
+// lane requests all of its (at most 16 per value: kMaxRowBlocks / 32) before it adds the first, in fixed order, so the
+// kernel is one memory round trip and not a chain of them (16 lanes with four loads in flight took eight trips).
 template <int NV, class E>
 __global__ void __launch_bounds__(256) colreduce_final(const double* partial, int nblk, int C, E epilogue) {
+  constexpr int COLS = 8, LANES = 32, PER = kMaxRowBlocks / LANES;
+  constexpr int GROUP = NV <= 2 ? PER : 8;         // blocks per lane requested together (registers: 2 per double)
   __shared__ double red[NV * 256];
-  const int cl = threadIdx.x & 15, q = threadIdx.x >> 4;
-  const int c = blockIdx.x * 16 + cl;
+  const int cl = threadIdx.x % COLS, q = threadIdx.x / COLS;
+  const int c = blockIdx.x * COLS + cl;
   double acc[NV];
 #pragma unroll
   for (int v = 0; v < NV; ++v) acc[v] = 0.0;
   if (c < C) {
-#pragma unroll 4
-    for (int b = q; b < nblk; b += 16) {
+    for (int b0 = q; b0 < nblk; b0 += LANES * GROUP) {
+      double t[NV][GROUP];
 #pragma unroll
-      for (int v = 0; v < NV; ++v) acc[v] += partial[((size_t)v * nblk + b) * C + c];
+      for (int u = 0; u < GROUP; ++u) {
+        const int b = b0 + LANES * u;
+#pragma unroll
+        for (int v = 0; v < NV; ++v) t[v][u] = b < nblk ? partial[((size_t)v * nblk + b) * C + c] : 0.0;
+      }
+#pragma unroll
+      for (int u = 0; u < GROUP; ++u)
+#pragma unroll
+        for (int v = 0; v < NV; ++v) acc[v] += t[v][u];
     }
   }
 #pragma unroll
@@ -110,7 +123,7 @@ __global__ void __launch_bounds__(256) colreduce_final(const double* partial, in
       const double* rr = red + v * 256 + cl;
       double s = 0.0;
 #pragma unroll
-      for (int j = 0; j < 16; ++j) s += rr[16 * j];
+      for (int j = 0; j < LANES; ++j) s += rr[COLS * j];
       tot[v] = s;
     }
     epilogue.template operator()<NV>(c, tot);
@@ -132,7 +145,7 @@ int run_colreduce_with(const char* who, F f, int M, int C, bool vec_ok, E epilog
   else
     hipLaunchKernelGGL((colreduce_partial<NV, 1, F>), grid, dim3(256), 0, st, f, M, C, rpb, partial);
   VG_CHECK_LAUNCH(who);
-  hipLaunchKernelGGL((colreduce_final<NV, E>), dim3((C + 15) / 16), dim3(256), 0, st, (const double*)partial, nb, C, epilogue);
+  hipLaunchKernelGGL((colreduce_final<NV, E>), dim3((C + 7) / 8), dim3(256), 0, st, (const double*)partial, nb, C, epilogue);
   VG_CHECK_LAUNCH(who);
   return VG_OK;
 }
