@@ -182,7 +182,7 @@ def test_h_forward_refuses_a_result_of_two_gib(gpu):
     assert b"2 GiB" in lib.vg_last_error()
 
 
-@pytest.mark.parametrize("shape,act", [((6, 64, 9, 7), 2), ((33, 128), 1), ((4, 24, 5, 5), 0), ((3, 7, 4, 4), 2)])
+@pytest.mark.parametrize("shape,act", [((6, 64, 9, 7), 2), ((33, 128), 1), ((4, 24, 5, 5), 0), ((3, 7, 4, 4), 2), ((6, 28, 9, 7), 2)])
 def test_norm_and_activation_h_kernels_equal_their_f32_twins(gpu, shape, act):
     """BatchNorm (statistics, apply, backward, double backward) and activation kernels on bf16 storage: all arithmetic is
     the f32 kernels' own, so the results are those of the f32 kernels on the widened values, rounded once at the
