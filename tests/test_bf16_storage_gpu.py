@@ -72,6 +72,7 @@ H_CONV_CASES = [
     (48, 64, 4, 4, 64, 3, 2, 1),       # 2 x 2 gradient: sixteen images per k-step
     (2, 16, 64, 64, 64, 3, 1, 1),      # 64-wide gradient: one row per k-step
     (1, 128, 32, 32, 64, 4, 2, 1),
+    (4, 16, 13, 13, 64, 5, 3, 1),      # stride 3: nine parity classes (no host table), 4 x 4 gradient, four images per k-step
 ]
 
 
