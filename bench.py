@@ -158,8 +158,9 @@ def measured_traffic(kernel):
 
 def launch_ranks(n, argv):
     """`python bench.py --gpus N` from a plain shell: start N fresh rank processes through torch.distributed.run as a
-    CHILD of this process, which has not touched the GPU and never will, pass their output through, and exit with
-    their status. (Replacing this process instead would be an exec; none is made.)"""
+    CHILD of this process, which has not touched the GPU and never will, and exit with their status (replacing this
+    process instead would be an exec; none is made). Of what the ranks write to stdout only the benchmark line reaches
+    this process's stdout; everything else (gloo announces its connections there) goes to stderr."""
     import socket
     import subprocess
     with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
@@ -167,7 +168,16 @@ def launch_ranks(n, argv):
         port = s.getsockname()[1]
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
-    return subprocess.call(cmd)
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True, bufsize=1)
+    try:
+        for line in proc.stdout:
+            out = sys.stdout if line.lstrip().startswith("{") else sys.stderr
+            out.write(line)
+            out.flush()
+    finally:
+        proc.stdout.close()
+        status = proc.wait()
+    return status
 
 
 def main():
