@@ -6,6 +6,7 @@
 #include <mutex>
 
 int vg_try_wgrad_stem(const vg_conv_geom* g, const float* gy, const float* x, float* slabs, int nslabs, hipStream_t st);
+int vg_stem_wgrad_applies(const vg_conv_geom* g);
 
 namespace {
 
@@ -253,6 +254,76 @@ extern "C" int vg_conv2d_wgrad_partial_h_multi(const vg_conv_geom* g, int pairs,
   if (pgemm_launch<MODE_WGRAD, 1>(pp, pl.bm, pl.bn, grid, (hipStream_t)stream) != 0)
     return vg_fail(VG_ERR_INVALID, "vg_conv2d_wgrad_partial_h_multi: no plane kernel for tile %dx%d", pl.bm, pl.bn);
   VG_CHECK_LAUNCH("vg_conv2d_wgrad_partial_h_multi");
+  return VG_OK;
+}
+
+// The same on f32 tensors (fp32 mode, the MFMA kernel; not the image stems, which have a kernel of their own).
+static WgradPlan wgrad_plan_multi(const vg_conv_geom* g, int pairs) {
+  return pairs <= 1 ? wgrad_plan(g) : wgrad_plan(g, (512 + pairs - 1) / pairs);
+}
+
+extern "C" int vg_conv2d_wgrad_multi_applies(const vg_conv_geom* g) {
+  if (vg_check_geom(g, "vg_conv2d_wgrad_multi_applies")) return 0;
+  if (vg_stem_wgrad_applies(g)) return 0;
+  return (long long)g->N * g->Ho * g->Wo * g->Co * 4 < (1LL << 31) && (long long)g->N * g->H * g->W * g->Ci * 4 < (1LL << 31);
+}
+
+extern "C" size_t vg_conv2d_wgrad_multi_workspace_bytes(const vg_conv_geom* g, int pairs) {
+  if (vg_check_geom(g, "vg_conv2d_wgrad_multi_workspace_bytes") || pairs < 1 || pairs > kMaxPairsH) return 0;
+  const WgradPlan pl = wgrad_plan_multi(g, pairs);
+  if (pl.nsplit * pairs <= 1) return 0;
+  return (size_t)pl.nsplit * pairs * pl.M * pl.Ncols * sizeof(float);
+}
+
+extern "C" int vg_conv2d_wgrad_reduce_multi(const vg_conv_geom* g, int pairs, float* gw, const void* workspace, void* stream) {
+  if (int e = vg_check_geom(g, "vg_conv2d_wgrad_reduce_multi")) return e;
+  VG_REQUIRE(pairs >= 1 && pairs <= kMaxPairsH, "vg_conv2d_wgrad_reduce_multi: one to four pairs");
+  const WgradPlan pl = wgrad_plan_multi(g, pairs);
+  if (pl.nsplit * pairs <= 1) return VG_OK;
+  VG_REQUIRE(gw && workspace, "vg_conv2d_wgrad_reduce_multi: null pointer");
+  launch_slab_reduce((const float*)workspace, gw, (size_t)pl.M * pl.Ncols, pl.nsplit * pairs, (hipStream_t)stream);
+  VG_CHECK_LAUNCH("vg_conv2d_wgrad_multi(slab reduce)");
+  return VG_OK;
+}
+
+extern "C" int vg_conv2d_wgrad_partial_multi(const vg_conv_geom* g, int pairs, const float* const* gy, const float* const* x,
+                                             float* gw, void* workspace, size_t workspace_bytes, void* stream) {
+  if (!vg_conv2d_wgrad_multi_applies(g))
+    return vg_fail(VG_ERR_INVALID, "vg_conv2d_wgrad_partial_multi: this geometry is not served (vg_conv2d_wgrad_multi_applies)");
+  VG_REQUIRE(pairs >= 1 && pairs <= kMaxPairsH && gy && x && gw, "vg_conv2d_wgrad_partial_multi: one to four pairs, no null pointers");
+  for (int i = 0; i < pairs; ++i) VG_REQUIRE(gy[i] && x[i], "vg_conv2d_wgrad_partial_multi: null tensor");
+  const WgradPlan pl = wgrad_plan_multi(g, pairs);
+  const int nsplit = pl.nsplit * pairs;
+  const size_t need = nsplit > 1 ? (size_t)nsplit * pl.M * pl.Ncols * sizeof(float) : 0;
+  if (need > 0 && (!workspace || workspace_bytes < need || !vg_aligned16(workspace)))
+    return vg_fail(VG_ERR_WORKSPACE, "vg_conv2d_wgrad_partial_multi: workspace of %zu bytes (16-byte aligned) required, got %zu",
+                   need, workspace_bytes);
+  IgemmParams p{};
+  p.A = gy[0]; p.B = x[0]; p.bias = nullptr;
+  p.out = nsplit > 1 ? (float*)workspace : gw;
+  p.N = g->N; p.H = g->H; p.W = g->W; p.Ci = g->Ci; p.Co = g->Co; p.KH = g->kh; p.KW = g->kw;
+  p.Ho = g->Ho; p.Wo = g->Wo; p.sh = g->sh; p.sw = g->sw; p.ph = g->ph; p.pw = g->pw;
+  p.M = pl.M; p.Ncols = pl.Ncols; p.Ktot = pl.Ktot;
+  p.mtiles = pl.mtiles; p.ntiles = pl.ntiles;
+  p.kchunk = pl.kchunk;
+  p.bias_mod = 1;
+  p.slab_stride = nsplit > 1 ? (long long)pl.M * pl.Ncols : 0;
+  bool a16 = true, b16 = true;
+  for (int i = 0; i < pairs; ++i) {
+    p.Aseg[i] = gy[i];
+    p.Bseg[i] = x[i];
+    a16 = a16 && vg_aligned16(gy[i]);
+    b16 = b16 && vg_aligned16(x[i]);
+  }
+  p.seg_splits = pl.nsplit;
+  const int va = (g->Co % 4 == 0 && a16) ? 4 : 1;
+  const int vb = (g->Ci % 4 == 0 && b16) ? 4 : 1;
+  if (igemm_set_operands(p, (long long)g->N * g->Ho * g->Wo * g->Co, (long long)g->N * g->H * g->W * g->Ci))
+    return vg_fail(VG_ERR_INVALID, "vg_conv2d_wgrad_partial_multi: gy or x is 2 GiB or larger");
+  dim3 grid((unsigned)(pl.mtiles * pl.ntiles), 1, (unsigned)nsplit);
+  if (igemm_launch<MODE_WGRAD, true>(p, pl.bm, pl.bn, va, vb, grid, (hipStream_t)stream, VG_PREC_F32) != 0)
+    return vg_fail(VG_ERR_INVALID, "vg_conv2d_wgrad_partial_multi: no kernel variant for bn=%d va=%d vb=%d", pl.bn, va, vb);
+  VG_CHECK_LAUNCH("vg_conv2d_wgrad_partial_multi");
   return VG_OK;
 }
 

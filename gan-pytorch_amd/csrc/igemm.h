@@ -71,6 +71,12 @@ struct IgemmParams {
     int cls_h, cls_w, off_h, off_w, Hc, Wc, nth, ntw, base_h, base_w;
     float inv_roww, inv_plane, inv_ntw;
   } cls[4];
+  // wgrad over several (gy, x) pairs of one geometry in one launch (the passes of a training step that share a layer):
+  // split z belongs to pair z / seg_splits and is split z % seg_splits of it; every split writes its own slab, so the
+  // slab sum is the sum over all pairs. seg_splits == 0: one pair, A / B.
+  const float* Aseg[4];
+  const float* Bseg[4];
+  int seg_splits;
 };
 
 // Fills p.cls for an input-gradient launch (strides whose sh * sw classes fit the table).
@@ -206,6 +212,7 @@ __global__ void __launch_bounds__(NW * 64, NW == 8 ? 4 : 1) igemm_kernel(const I
   // ---- per-mode extents -------------------------------------------------------------------
   int M = p.M, Ktot = p.Ktot;
   int kbeg = 0, kend = p.Ktot;
+  const float *opA = p.A, *opB = p.B;          // this block's operands
   // dgrad parity class
   int cls_h = 0, cls_w = 0, off_h = 0, off_w = 0, Hc = 0, Wc = 0, nth = 0, ntw = 0, base_h = 0, base_w = 0;
   float tab_inv_roww = 0.f, tab_inv_plane = 0.f, tab_inv_ntw = 0.f;
@@ -239,7 +246,16 @@ __global__ void __launch_bounds__(NW * 64, NW == 8 ? 4 : 1) igemm_kernel(const I
       return;
     }
   } else if constexpr (MODE == MODE_WGRAD) {
-    kbeg = zz * p.kchunk;
+    int zl = zz;
+    if (p.seg_splits > 0) {
+      const int seg = zz / p.seg_splits;
+      zl = zz - seg * p.seg_splits;
+      // (constant indices: a dynamically indexed array of a by-value kernel argument sends the whole structure to
+      // scratch memory)
+      opA = seg == 0 ? p.Aseg[0] : seg == 1 ? p.Aseg[1] : seg == 2 ? p.Aseg[2] : p.Aseg[3];
+      opB = seg == 0 ? p.Bseg[0] : seg == 1 ? p.Bseg[1] : seg == 2 ? p.Bseg[2] : p.Bseg[3];
+    }
+    kbeg = zl * p.kchunk;
     kend = min(kbeg + p.kchunk, p.Ktot);
   } else {
     ntw = p.KW;
@@ -436,8 +452,8 @@ __global__ void __launch_bounds__(NW * 64, NW == 8 ? 4 : 1) igemm_kernel(const I
   // with the top bit set: that is beyond any operand (both are smaller than 2 GiB), and the hardware returns zeros for
   // it. So a tile's loads are one straight-line sequence without branches, selects on 64-bit pointers or a dummy page.
   constexpr unsigned OOB = 0x80000000u;
-  const __amdgpu_buffer_rsrc_t rsrcA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.A), 0, (int)p.a_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rsrcB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.B), 0, (int)p.b_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrcA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(opA), 0, (int)p.a_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrcB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(opB), 0, (int)p.b_bytes, 0x00020000);
   auto ld4 = [&](const __amdgpu_buffer_rsrc_t& rs, unsigned off) -> f32x4 {
     return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)off, 0, 0));
   };

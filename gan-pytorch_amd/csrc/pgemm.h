@@ -155,8 +155,10 @@ __global__ void __launch_bounds__(NW * 64, (NP == 1 && NW == 8 && MODE != MODE_W
     if (pp.seg_splits > 0) {
       const int seg = zz / pp.seg_splits;
       zl = zz - seg * pp.seg_splits;
-      opA = pp.Aseg[seg];
-      opB = pp.Bseg[seg];
+      // (constant indices: a dynamically indexed array of a by-value kernel argument sends the whole structure to
+      // scratch memory)
+      opA = seg == 0 ? pp.Aseg[0] : seg == 1 ? pp.Aseg[1] : seg == 2 ? pp.Aseg[2] : pp.Aseg[3];
+      opB = seg == 0 ? pp.Bseg[0] : seg == 1 ? pp.Bseg[1] : seg == 2 ? pp.Bseg[2] : pp.Bseg[3];
     }
     kbeg = zl * p.kchunk;
     kend = min(kbeg + p.kchunk, p.Ktot);

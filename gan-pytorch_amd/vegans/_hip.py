@@ -57,6 +57,10 @@ SIGNATURES = {
     "vg_conv2d_wgrad_noalloc": (c_int, [_G, _P, _P, _P, _P]),
     "vg_conv2d_wgrad_partial": (c_int, [_G, _P, _P, _P, _P, c_size_t, _P]),
     "vg_conv2d_wgrad_reduce": (c_int, [_G, _P, _P, _P]),
+    "vg_conv2d_wgrad_multi_applies": (c_int, [_G]),
+    "vg_conv2d_wgrad_multi_workspace_bytes": (c_size_t, [_G, c_int]),
+    "vg_conv2d_wgrad_partial_multi": (c_int, [_G, c_int, _P, _P, _P, _P, c_size_t, _P]),
+    "vg_conv2d_wgrad_reduce_multi": (c_int, [_G, c_int, _P, _P, _P]),
     "vg_conv2d_variant": (c_int, [c_int, _G, ctypes.c_char_p, c_size_t]),
     "vg_conv2d_fwd_act_applies": (c_int, [_G, c_int]),
     "vg_conv2d_fwd_act": (c_int, [_G, _P, _P, _P, _P, c_int, c_float, _P]),

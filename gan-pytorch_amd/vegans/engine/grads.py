@@ -139,6 +139,8 @@ class Ledger:
         self.params = [p for p in params if p.requires_grad]
         self.index = {id(p): p for p in self.params}
         self.entries = {}
+        self.counts = {}     # id(param) -> contributions received (a gradient left from an earlier pass included); the
+                             # rows of `entries` are fewer once pending contractions have been run together
         self.sink = sink
         self.summer = summer if summer is not None else sum_into    # host-logic tests pass a CPU stand-in
         self.done = set()
@@ -157,6 +159,7 @@ class Ledger:
             if p.grad is not None:
                 # a gradient left from an earlier backward pass is the first term, as it is for torch's accumulation
                 self.entries[id(p)] = [((), p.grad)]
+                self.counts[id(p)] = 1
         _active = self
         return self
 
@@ -173,11 +176,12 @@ class Ledger:
             raise _hip.HipError("a gradient contribution arrived after its parameter's bucket had been handed to the "
                                 "all-reduce: the model's backward graph changed between two iterations")
         self.entries.setdefault(key, []).append((label, grad.detach()))
+        self.counts[key] = self.counts.get(key, 0) + 1
         if _needs_events(grad):
             # produced on whatever stream this backward node runs on; the summation waits for it (flush)
             self.events.setdefault(key, []).append(_record_event())
         if self.sink is not None:
-            self.sink.deposited(self, param, len(self.entries[key]))
+            self.sink.deposited(self, param, self.counts[key])
 
     def materialize(self, param):
         """Run the contractions the operators left behind for `param` (ops.PendingWgrad): the pending pairs of one

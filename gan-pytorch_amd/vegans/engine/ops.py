@@ -783,13 +783,13 @@ class PendingWgrad:
     the gradient ledger, which runs the pairs of a layer in ONE contraction when it sums that layer's contributions
     (`wgrad_of_pairs`). On bf16 tensors a weight-gradient launch of these layers is bound by its fixed costs and its
     slab traffic, not by its flops: four passes in one launch take 2.6 times one (measured, batch 256)."""
-    __slots__ = ("g", "gy", "x", "w_shape", "key")
+    __slots__ = ("g", "gy", "x", "w_shape", "key", "half")
     pending = True
     is_cuda = True
 
-    def __init__(self, g, gy, x, w_shape):
-        self.g, self.gy, self.x, self.w_shape = g, gy, x, w_shape
-        self.key = (g.N, g.H, g.W, g.Ci, g.Co, g.kh, g.kw, g.sh, g.sw, g.ph, g.pw, g.flat, tuple(w_shape))
+    def __init__(self, g, gy, x, w_shape, half):
+        self.g, self.gy, self.x, self.w_shape, self.half = g, gy, x, w_shape, half      # half: bf16 tensors
+        self.key = (g.N, g.H, g.W, g.Ci, g.Co, g.kh, g.kw, g.sh, g.sw, g.ph, g.pw, g.flat, tuple(w_shape), half)
 
     def detach(self):
         return self
@@ -809,30 +809,36 @@ def wgrad_of_pairs(items):
         gw = torch.empty(w_shape, dtype=torch.float32, device=dev)
     if gw.numel() != g.w_numel():
         raise _hip.HipError("weight gradient shape %s does not match the geometry" % (tuple(w_shape),))
-    nbytes = _hip.load().vg_conv2d_wgrad_h_multi_workspace_bytes(ctypes.byref(g.c), n)
+    names = (("vg_conv2d_wgrad_h_multi_workspace_bytes", "vg_conv2d_wgrad_partial_h_multi", "vg_conv2d_wgrad_reduce_h_multi")
+             if items[0].half else
+             ("vg_conv2d_wgrad_multi_workspace_bytes", "vg_conv2d_wgrad_partial_multi", "vg_conv2d_wgrad_reduce_multi"))
+    nbytes = getattr(_hip.load(), names[0])(ctypes.byref(g.c), n)
     wsp = ctypes.c_void_p(workspace(nbytes, dev).data_ptr()) if nbytes else None
     gys = (ctypes.c_void_p * n)(*[t.gy.data_ptr() for t in items])
     xs = (ctypes.c_void_p * n)(*[t.x.data_ptr() for t in items])
     # (for the benchmark's per-launch timer the launch counts as one over n times the rows)
     timed_as = g if n == 1 else Geom(g.N * n, g.H, g.W, g.Ci, g.Co, g.kh, g.kw, g.sh, g.sw, g.ph, g.pw, g.flat)
-    _launch_conv(2, timed_as, lambda: call("vg_conv2d_wgrad_partial_h_multi", ctypes.byref(g.c), n, gys, xs, _ptr(gw), wsp,
-                                           c_size_t(nbytes), _stream()))
+    _launch_conv(2, timed_as, lambda: call(names[1], ctypes.byref(g.c), n, gys, xs, _ptr(gw), wsp, c_size_t(nbytes), _stream()))
     if nbytes:
-        call("vg_conv2d_wgrad_reduce_h_multi", ctypes.byref(g.c), n, _ptr(gw), wsp, _stream())
+        call(names[2], ctypes.byref(g.c), n, _ptr(gw), wsp, _stream())
     return gw
 
 
 def _weight_gradient(w, lab, gy, x, g):
     """The contribution conv_wgrad(gy, x) to d loss / d w, routed to the gradient ledger (None) or returned for autograd.
-    In the bf16 data path, inside a backward pass that builds no graph, with a ledger collecting for `w`, the
-    contraction is left to the ledger (PendingWgrad); VEGANS_HIP_MERGED_WGRAD=0 switches that off."""
-    if (_mode == "bf16" and grads.accepts(w) and not torch.is_grad_enabled() and gy.dtype == BF16 and x.dtype == BF16
-            and gy.is_cuda and os.environ.get("VEGANS_HIP_MERGED_WGRAD", "1") != "0"
-            and _hip.load().vg_conv2d_h_applies(2, ctypes.byref(g.c))):
-        gy_m, x_m = to_nhwc(gy), to_nhwc(x)
-        _check_shape(gy_m, g.y_shape(), "conv output-side tensor")
-        _check_shape(x_m, g.x_shape(), "conv input")
-        return grads.route(w, lab, PendingWgrad(g, gy_m, x_m, tuple(w.shape)))
+    In the fp32 mode and the bf16 data path, inside a backward pass that builds no graph, with a ledger collecting for
+    `w`, the contraction is left to the ledger (PendingWgrad); VEGANS_HIP_MERGED_WGRAD=0 switches that off."""
+    if (grads.accepts(w) and not torch.is_grad_enabled() and gy.is_cuda and _mode in ("bf16", "fp32")
+            and os.environ.get("VEGANS_HIP_MERGED_WGRAD", "1") != "0"):
+        half = _mode == "bf16" and gy.dtype == BF16 and x.dtype == BF16 and bool(
+            _hip.load().vg_conv2d_h_applies(2, ctypes.byref(g.c)))
+        full = _mode == "fp32" and gy.dtype == F32 and x.dtype == F32 and bool(
+            _hip.load().vg_conv2d_wgrad_multi_applies(ctypes.byref(g.c)))
+        if half or full:
+            gy_m, x_m = to_nhwc(gy), to_nhwc(x)
+            _check_shape(gy_m, g.y_shape(), "conv output-side tensor")
+            _check_shape(x_m, g.x_shape(), "conv input")
+            return grads.route(w, lab, PendingWgrad(g, gy_m, x_m, tuple(w.shape), half))
     return grads.route(w, lab, ConvWgradFn.apply(gy, x, g, tuple(w.shape), lab + (1,)))
 
 

@@ -179,7 +179,7 @@ class GradReducer:
 
     def closed(self, ledger):
         """The backward pass is over and the ledger has written every parameter that received a gradient."""
-        seen = {key: len(rows) for key, rows in ledger.entries.items()}
+        seen = dict(ledger.counts)
         for p in self.params:
             if id(p) in seen:
                 self.touched[self.where[id(p)][0]] = True

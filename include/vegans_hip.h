@@ -83,6 +83,18 @@ int vg_conv2d_fwd_act(const vg_conv_geom* g, const float* x, const float* w, con
 int vg_conv2d_wgrad_partial(const vg_conv_geom* g, const float* gy, const float* x, float* gw,
                             void* workspace, size_t workspace_bytes, void* stream);
 int vg_conv2d_wgrad_reduce(const vg_conv_geom* g, float* gw, const void* workspace, void* stream);
+/* The weight gradient of one layer summed over `pairs` (1..4) pairs (gy[i], x[i]) of one geometry in one launch: what
+ * the reference's optimizer finds in weight.grad after every pass of a training step that ran through the layer has
+ * back-propagated (WassersteinGANGP.py:88-107: fake batch, real batch, and the penalty's double backward twice;
+ * torch's AccumulateGrad adds them one by one). gy and x are host arrays of device pointers. The splits of the launch
+ * are dealt out over the pairs, so the slab traffic and the slab sum are those of a single pass; the slabs are added
+ * in pair order, split order within a pair. vg_conv2d_wgrad_multi_applies: f32 tensors below 2 GiB, not the image-stem
+ * geometries (those have a kernel of their own). */
+int vg_conv2d_wgrad_multi_applies(const vg_conv_geom* g);
+size_t vg_conv2d_wgrad_multi_workspace_bytes(const vg_conv_geom* g, int pairs);
+int vg_conv2d_wgrad_partial_multi(const vg_conv_geom* g, int pairs, const float* const* gy, const float* const* x, float* gw,
+                                  void* workspace, size_t workspace_bytes, void* stream);
+int vg_conv2d_wgrad_reduce_multi(const vg_conv_geom* g, int pairs, float* gw, const void* workspace, void* stream);
 
 /* vg_conv2d_wgrad for callers that cannot allocate device memory or hand over a workspace (code running under HIP graph
  * capture, tight serving loops, harnesses that forbid hipMalloc). It has no counterpart in the reference. Same

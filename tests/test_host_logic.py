@@ -298,6 +298,29 @@ def test_ledger_runs_pending_weight_gradients_grouped_by_geometry(monkeypatch):
     assert torch.equal(p.grad, torch.full((2,), 127.5))
     assert not grads.accepts(p)
 
+    # a data-parallel sink counts contributions as they arrive, not the rows left after pairs were run together
+    class Sink:
+        weight = 1.0
+
+        def __init__(self):
+            self.seen, self.final = [], None
+
+        def deposited(self, ledger, param, n_so_far):
+            self.seen.append(n_so_far)
+
+        def slot(self, param):
+            return torch.zeros(2)
+
+        def closed(self, ledger):
+            self.final = dict(ledger.counts)
+
+    sink = Sink()
+    q = torch.nn.Parameter(torch.zeros(2))
+    with grads.Ledger([q], sink=sink, summer=summer):
+        for lab in ((1,), (2,), (3,)):
+            grads.route(q, lab, Pending("a", 1.0))
+    assert sink.seen == [1, 2, 3] and sink.final == {id(q): 3}
+
 
 def test_ledger_orders_sums_and_collectives_across_streams(monkeypatch):
     """Parameters that complete on alternating streams (the critic's fake / real / penalty chains run their backward

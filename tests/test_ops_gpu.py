@@ -802,6 +802,43 @@ def test_kernel_timing_events_hold_the_kernels_own_duration(gpu):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("case,pairs", [((2, 64, 16, 16, 128, 4, 2, 1), 4), ((3, 16, 9, 7, 24, 3, 1, 1), 3),
+                                        ((5, 6, 20, 20, 64, 4, 2, 1), 2), ((2, 96, 6, 6, 40, 5, 2, 2), 1)])
+def test_weight_gradient_over_several_pairs_in_one_launch(gpu, case, pairs):
+    """vg_conv2d_wgrad_partial_multi + vg_conv2d_wgrad_reduce_multi: the weight gradient of one layer summed over several
+    (gy, x) pairs, against the sum of torch's weight gradients on the CPU."""
+    import ctypes
+    from vegans import _hip
+    from vegans.engine import ops
+    N, Ci, H, W, Co, k, s, p = case
+    lib = _hip.load()
+    gen = torch.Generator().manual_seed(sum(case) + pairs)
+    geo = ops.Geom(N, H, W, Ci, Co, k, k, s, s, p, p)
+    assert lib.vg_conv2d_wgrad_multi_applies(ctypes.byref(geo.c))
+    CL = torch.channels_last
+    want = torch.zeros(Co, Ci, k, k)
+    xs, gs = [], []
+    for _ in range(pairs):
+        x = torch.randn(N, Ci, H, W, generator=gen)
+        gy = torch.randn(N, Co, geo.Ho, geo.Wo, generator=gen)
+        want += torch.nn.grad.conv2d_weight(x, (Co, Ci, k, k), gy, stride=s, padding=p)
+        xs.append(x.to(gpu).contiguous(memory_format=CL))
+        gs.append(gy.to(gpu).contiguous(memory_format=CL))
+    gw = torch.empty((Co, Ci, k, k), dtype=torch.float32, device=gpu, memory_format=CL)
+    nbytes = lib.vg_conv2d_wgrad_multi_workspace_bytes(ctypes.byref(geo.c), pairs)
+    ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=gpu)
+    P = lambda t: ctypes.c_void_p(t.data_ptr())
+    gptr = (ctypes.c_void_p * pairs)(*[t.data_ptr() for t in gs])
+    xptr = (ctypes.c_void_p * pairs)(*[t.data_ptr() for t in xs])
+    st = _hip._stream()
+    _hip.call("vg_conv2d_wgrad_partial_multi", ctypes.byref(geo.c), pairs, gptr, xptr, P(gw), P(ws), ctypes.c_size_t(nbytes), st)
+    _hip.call("vg_conv2d_wgrad_reduce_multi", ctypes.byref(geo.c), pairs, P(gw), P(ws), st)
+    _close(gw, want, what="weight gradient over %d pairs" % pairs)
+    stem = ops.Geom(4, 64, 64, 3, 64, 4, 4, 2, 2, 1, 1)
+    assert not lib.vg_conv2d_wgrad_multi_applies(ctypes.byref(stem.c))
+    assert lib.vg_conv2d_wgrad_partial_multi(ctypes.byref(geo.c), 5, gptr, xptr, P(gw), P(ws), ctypes.c_size_t(nbytes), st) == -1
+
+
 def test_eight_wave_kernels_are_not_given_factors_beyond_24_bits(gpu):
     """The eight-wave f32 contraction kernels form their address products with 24-bit multiplies; a problem with 2^23 or
     more pixels (or any other factor that large) has to run on the four-wave variants, which multiply in 32 bits. The
