@@ -264,6 +264,49 @@ def test_three_runs_are_bit_identical(gpu):
                 assert torch.equal(runs[0][2][k], other[2][k]), k
 
 
+@pytest.mark.parametrize("mode", ["fp32", "bf16"])
+def test_merged_weight_gradients_agree_with_one_launch_per_contribution(gpu, monkeypatch, mode):
+    """The weight-gradient contributions of a layer run as one contraction when the ledger sums them (the default), or
+    each in its own launch (VEGANS_HIP_MERGED_WGRAD=0): the same sums in another order. The gradients the first two
+    optimizer steps receive agree to f32 summation noise, and the merged path really ran."""
+    import bench_configs as cfg
+    from vegans.engine import ops
+    B = 8
+    data = cfg.synthetic_images(B, (3, 16, 16), seed=8)
+    z = torch.randn(B, 16, 1, 1, generator=torch.Generator().manual_seed(12))
+    previous = ops.set_matmul_precision(mode)
+    try:
+        seen, merged_launches = {}, []
+        plain_pairs = ops.wgrad_of_pairs
+
+        def counting(items):
+            merged_launches.append(len(items))
+            return plain_pairs(items)
+
+        monkeypatch.setattr(ops, "wgrad_of_pairs", counting)
+        for flag in ("1", "0"):
+            monkeypatch.setenv("VEGANS_HIP_MERGED_WGRAD", flag)
+            m = _model("WassersteinGANGP", width=16)
+            grads_seen = []
+            plain = m._step
+
+            def step(who=None, plain=plain, m=m, grads_seen=grads_seen):
+                grads_seen.append([p.grad.detach().float().clone() for p in m.neural_nets[who].parameters()])
+                plain(who=who)
+
+            m._step = step
+            _run(m, [m._to_device(data)], [z.to("cuda")], False)
+            seen[flag] = grads_seen
+        assert merged_launches and max(merged_launches) >= 3, merged_launches
+        tol = 2e-5 if mode == "fp32" else 2e-3
+        for a, b in zip(seen["1"], seen["0"]):
+            for ga, gb in zip(a, b):
+                scale = max(float(gb.abs().max()), 1e-12)
+                assert float((ga - gb).abs().max()) <= tol * scale
+    finally:
+        ops.set_matmul_precision(previous)
+
+
 def test_captured_graph_survives_a_larger_scratch_buffer(gpu):
     """The recorded kernels hold the address of the shared scratch buffer. A later eager call that needs more scratch
     replaces the buffer; the graph must keep the one it recorded alive and still replay bit for bit."""
